@@ -1,0 +1,172 @@
+/*
+ * rmhip.h -- C ABI of librmhip.so: the MI355X (gfx950) replacement for the
+ * fragment-shader march of the Unity project symbiosinx/Raymarching.
+ *
+ * The reference drives its shader through Unity's Material property bag and a
+ * full-screen blit:
+ *     mat.SetMatrix("_FrustrumCorners", ...) ... Graphics.Blit(src, dest, mat)
+ *                                      (Assets/Raymarching.cs:85-95)
+ *     shadowMapMaterial.SetMatrix(...); Graphics.Blit(r, shadowMap, mat)
+ *                                      (Assets/ShadowMap.cs:50-56)
+ * This header is that boundary as plain C: an rm_ctx is one material bound to
+ * one GPU, rm_set_* are Material.Set*, rm_blit* are Graphics.Blit.
+ *
+ * Conventions
+ *  - Matrices are float[16] in Unity's Matrix4x4 field order (column-major:
+ *    m00,m10,m20,m30,m01,...).  The shader reads M[i] as row i =
+ *    {m[i], m[i+4], m[i+8], m[i+12]} (Assets/Raymarching.cginc:30,336-354).
+ *  - Images are row-major with row 0 = BOTTOM row (blit uv origin is bottom-left,
+ *    Assets/Raymarching.cginc:30 with Assets/Raymarching.cs:50-53).
+ *  - Property names are the shader's, case-sensitive.  Unknown names are stored
+ *    and ignored, as Unity does.
+ *  - Every entry point returns 0 on success or a negative RM_E_* code; the
+ *    message is available from rm_last_error().  Nothing throws or aborts.
+ *  - A context is not re-entrant: one thread at a time, one context per GPU.
+ */
+#ifndef RMHIP_H
+#define RMHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RM_OK            0
+#define RM_E_ARG        -1   /* null/invalid argument */
+#define RM_E_DEVICE     -2   /* HIP runtime error (no GPU, launch failure, ...) */
+#define RM_E_NOMEM      -3
+#define RM_E_RANGE      -4   /* size beyond a documented limit */
+
+#define RM_MAX_PRIMS   1024
+
+typedef struct rm_ctx rm_ctx;
+
+/* primitive kinds in the order scene() uses them (Assets/Raymarching.cginc:351-354);
+ * torus is the reference's unused fifth primitive (cginc:179-182) */
+enum { RM_SPHERE = 0, RM_BOX = 1, RM_LINK = 2, RM_CYLINDER = 3, RM_TORUS = 4 };
+
+/* One scene primitive for rm_set_primitives(): generalises the four rows of
+ * _Positions/_Rotations/_Scales (Assets/Raymarching.cs:58-83) beyond the
+ * reference's 4-slot limit (Assets/Raymarching.cs:60). */
+typedef struct {
+    int32_t type;       /* RM_* */
+    int32_t op;         /* reserved, 0 = smooth union (smin, cginc:110-113) */
+    float   pos[3];
+    float   quat[4];    /* x,y,z,w */
+    float   scale[3];
+    float   color[3];
+    float   params[4];  /* sphere r | box b.xyz | link le,r1,r2 | cylinder h,r | torus t.x,t.y */
+} rm_primitive;
+
+/* counters of the last blit / depth pass (all ranks of work the call covered) */
+typedef struct {
+    uint64_t n_pixels;       /* primary rays */
+    uint64_t n_hit;          /* hit pixels = shadow rays */
+    uint64_t sum_steps_p;    /* scene() evaluations of all primary marches */
+    uint64_t sum_steps_s;    /* scene() evaluations of all shadow marches  */
+} rm_stats;
+
+/* ---- life cycle ---------------------------------------------------------
+ * Replaces: the Material asset + its shader (Assets/Raymarching.mat,
+ * Assets/ShadowMap.mat).  The context starts with the values serialized in
+ * Assets/Raymarching.mat:62-95 and the default scene of
+ * Assets/Scenes/SampleScene.unity.  No GPU call is made until the first
+ * blit, so property-bag use works on a machine without a GPU. */
+rm_ctx     *rm_create(int hip_device);
+void        rm_destroy(rm_ctx *ctx);
+const char *rm_last_error(rm_ctx *ctx);         /* ctx may be NULL: last creation error */
+const char *rm_version(void);
+
+/* ---- Material.SetFloat / SetInt / SetVector / SetMatrix -----------------
+ * Replaces: mat.SetMatrix(name, Matrix4x4) at Assets/Raymarching.cs:86-90 and
+ * Assets/ShadowMap.cs:52-53, and the inspector-serialized floats of
+ * Assets/Raymarching.mat:62-95 declared at Assets/Raymarching.cginc:1-13 and
+ * Assets/Raymarching.shader:30-46.  Unity built-ins the shader reads are explicit
+ * properties here: _WorldSpaceCameraPos (shader:167), _WorldSpaceLightPos0
+ * (shader:109,199), _ProjectionParams (shader:154).  _BackgroundColor (rgba in
+ * [0,1]) stands in for _MainTex when rm_blit gets no source image. */
+int rm_set_float (rm_ctx *ctx, const char *name, float value);
+int rm_set_int   (rm_ctx *ctx, const char *name, int value);
+int rm_set_vector(rm_ctx *ctx, const char *name, const float v[4]);
+int rm_set_matrix(rm_ctx *ctx, const char *name, const float m[16]);
+/* Material.GetFloat / GetInt / GetVector / GetMatrix; RM_E_ARG if never set */
+int rm_get_float (rm_ctx *ctx, const char *name, float *value);
+int rm_get_int   (rm_ctx *ctx, const char *name, int *value);
+int rm_get_vector(rm_ctx *ctx, const char *name, float v[4]);
+int rm_get_matrix(rm_ctx *ctx, const char *name, float m[16]);
+/* Material.HasProperty: 1 if the march reads this name, 0 if it is only stored */
+int rm_has_property(rm_ctx *ctx, const char *name);
+
+/* N-primitive scene (n = 0 returns to the 4-row matrices).  Extends
+ * GetPositions/GetRotations/GetScales (Assets/Raymarching.cs:58-83); the tree is
+ * the balanced pairwise smin of Assets/Raymarching.cginc:363 in index order. */
+int rm_set_primitives(rm_ctx *ctx, const rm_primitive *prims, int n);
+
+/* ---- Graphics.Blit(src, dest, mat) --------------------------------------
+ * Replaces: Assets/Raymarching.cs:94 + pass 0 of Assets/Raymarching.shader
+ * (frag, :149-216).  Host-pointer form; synchronous.  src_rgba8 (the _MainTex
+ * the shader shows on miss pixels) and scene_depth (linear eye depth, the
+ * shader's Linear01Depth(..)*_ProjectionParams.z, :154) may be NULL.  Outputs:
+ * RGBA8 colour (alpha 255), fp32 depth = r.length, optional 0/1 hit mask; any
+ * may be NULL. */
+int rm_blit(rm_ctx *ctx, const uint8_t *src_rgba8, const float *scene_depth,
+            uint8_t *dst_rgba8, float *dst_depth, uint8_t *dst_hit, int w, int h);
+
+/* Same blit on device pointers, asynchronous on `hip_stream` (a hipStream_t; NULL
+ * = the default stream).  This is the form a Unity native plugin uses with
+ * Texture.GetNativeTexturePtr-style buffers already resident in HBM. */
+int rm_blit_device(rm_ctx *ctx, const void *d_src_rgba8, const void *d_scene_depth,
+                   void *d_dst_rgba8, void *d_dst_depth, void *d_dst_hit,
+                   int w, int h, void *hip_stream);
+
+/* Row-band shard of one frame for multi-GPU rendering: renders the rows y of the
+ * w x h frame with (y / band_rows) % n_parts == part into COMPACT buffers that
+ * hold only those rows, in increasing y.  rm_band_rows() gives their count.
+ * src/scene_depth, if given, are full-frame device buffers. */
+int rm_band_rows(int h, int band_rows, int part, int n_parts);
+int rm_blit_bands_device(rm_ctx *ctx, const void *d_src_rgba8, const void *d_scene_depth,
+                         void *d_dst_rgba8, void *d_dst_depth, void *d_dst_hit,
+                         int w, int h, int band_rows, int part, int n_parts, void *hip_stream);
+
+/* Batch of camera poses in one call: pose i uses frustum_corners[i*16..] and
+ * cam_inv_view[i*16..] (both as rm_set_matrix takes them) and cam_pos[i*3..];
+ * outputs are n_poses consecutive frames.  Replaces n_poses x (SetMatrix x2 +
+ * Blit) of Assets/Raymarching.cs:86-94. */
+int rm_blit_poses_device(rm_ctx *ctx, int n_poses, const float *frustum_corners,
+                         const float *cam_inv_view, const float *cam_pos,
+                         void *d_dst_rgba8, void *d_dst_depth, void *d_dst_hit,
+                         int w, int h, void *hip_stream);
+
+/* ---- ShadowMap.Render() --------------------------------------------------
+ * Replaces: Assets/ShadowMap.cs:50-56 (SetMatrix x2 + Blit into `shadowMap`).
+ * The reference's ShadowMap fragment is a colour-inverting stub
+ * (Assets/ShadowMap.shader:20-25); here the pass is raymarch()
+ * (Assets/Raymarching.cginc:367-392) from _WorldSpaceCameraPos along the rays
+ * _FrustrumCorners/_CameraInvViewMatrix define, writing r.length. */
+int rm_shadowmap_render(rm_ctx *ctx, float *dst_depth, int w, int h);
+int rm_shadowmap_render_device(rm_ctx *ctx, void *d_dst_depth, void *d_dst_hit,
+                               int w, int h, void *hip_stream);
+
+/* ---- ShadowMapDirectional ------------------------------------------------
+ * Replaces: the rectangle Assets/ShadowMapDirectional.cs:25-34 computes
+ * (corners in its order TL,TR,BR,BL, :11-16) as an orthographic depth pass:
+ * ray origin bilinear over the corners, direction `forward`, raymarch(). */
+int rm_shadowmap_directional(rm_ctx *ctx, const float corners[12], const float forward[3],
+                             float *dst_depth, int w, int h);
+int rm_shadowmap_directional_device(rm_ctx *ctx, const float corners[12], const float forward[3],
+                                    void *d_dst_depth, void *d_dst_hit,
+                                    int w, int h, void *hip_stream);
+
+/* ---- counters -------------------------------------------------------------
+ * No counterpart in the reference (its nearest thing is the commented-out
+ * step-count heat map, Assets/Raymarching.shader:203).  rm_get_stats waits for
+ * the stream of the last call and returns that call's counters. */
+int rm_get_stats(rm_ctx *ctx, rm_stats *out);
+/* kernel variant for the next blits: 0 = auto */
+int rm_set_kernel(rm_ctx *ctx, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RMHIP_H */

@@ -1,0 +1,513 @@
+/*
+ * rm_oracle.c -- CPU restatement of the reference's fragment-shader march.
+ *
+ * TEST INFRASTRUCTURE ONLY (see rm_oracle.h).  PARITY UNPINNED BY THE REFERENCE.
+ *
+ * Each function cites the reference lines it restates, relative to the
+ * reference checkout (Assets/Raymarching.cginc = "cginc", Assets/Raymarching.shader
+ * = "shader", the C# scripts by file name).  Build: see oracle/Makefile
+ * (gcc -O2 -ffp-contract=off -fno-fast-math).
+ */
+#define _GNU_SOURCE
+#include "rm_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdatomic.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+typedef struct { float x, y, z; } f3;
+typedef struct { float x, y, z, w; } f4;
+
+/* ---- canonical intrinsic expansions ------------------------------------ */
+static inline f3 v3(float x, float y, float z) { f3 r = {x, y, z}; return r; }
+static inline f3 add3(f3 a, f3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline f3 sub3(f3 a, f3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline f3 mul3(f3 a, f3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline f3 div3(f3 a, f3 b) { return v3(a.x / b.x, a.y / b.y, a.z / b.z); }
+static inline f3 scl3(f3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+static inline f3 neg3(f3 a) { return v3(-a.x, -a.y, -a.z); }
+static inline float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline float dot2(float ax, float ay, float bx, float by) { return ax * bx + ay * by; }
+static inline float len3(f3 a) { return sqrtf(dot3(a, a)); }
+static inline float len2(float x, float y) { return sqrtf(dot2(x, y, x, y)); }
+static inline f3 cross3(f3 a, f3 b) {
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline f3 normalize3(f3 a) { float r = 1.0f / sqrtf(dot3(a, a)); return scl3(a, r); }
+static inline float lerp1(float a, float b, float t) { return a + t * (b - a); }
+static inline f3 lerp3(f3 a, f3 b, float t) {
+    return v3(lerp1(a.x, b.x, t), lerp1(a.y, b.y, t), lerp1(a.z, b.z, t));
+}
+static inline float clamp1(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+/* row i of a column-major Unity Matrix4x4 (the shader's M[i], cginc:30,336-354) */
+static inline f4 mrow(const float *m, int i) { f4 r = {m[i], m[i + 4], m[i + 8], m[i + 12]}; return r; }
+static inline f3 xyz(f4 a) { return v3(a.x, a.y, a.z); }
+
+/* ---- cginc:62-66  rotate(float3 v, float4 q) ---------------------------- */
+static inline f3 rotate_q(f3 v, f4 q) {
+    f3 u = neg3(xyz(q));
+    f3 t1 = scl3(u, 2.0f * dot3(u, v));
+    f3 t2 = scl3(v, q.w * q.w - dot3(u, u));
+    f3 t3 = scl3(cross3(u, v), 2.0f * q.w);
+    return add3(add3(t1, t2), t3);
+}
+
+/* ---- cginc:76-78  min(float3) ------------------------------------------- */
+static inline float min3(f3 a) { return fminf(a.x, fminf(a.y, a.z)); }
+
+/* ---- cginc:80-82  remap -------------------------------------------------- */
+static inline float remap(float x, float o1, float o2, float n1, float n2) {
+    return (x - o1) / (o2 - o1) * (n2 - n1) + n1;
+}
+
+/* ---- cginc:169-171  sphere ----------------------------------------------- */
+static inline float sd_sphere(f3 p, float r) { return len3(p) - r * .5f; }
+
+/* ---- cginc:173-177  box -------------------------------------------------- */
+static inline float sd_box(f3 p, f3 b) {
+    b = scl3(b, .5f);
+    f3 d = v3(fabsf(p.x) - b.x, fabsf(p.y) - b.y, fabsf(p.z) - b.z);
+    f3 dm = v3(fmaxf(d.x, 0.0f), fmaxf(d.y, 0.0f), fmaxf(d.z, 0.0f));
+    return len3(dm) + fminf(fmaxf(d.x, fmaxf(d.y, d.z)), 0.0f);
+}
+
+/* ---- cginc:179-182  torus ------------------------------------------------ */
+static inline float sd_torus(f3 p, float tx, float ty) {
+    float qx = len2(p.x, p.y) - tx;
+    return len2(qx, p.z) - ty;
+}
+
+/* ---- cginc:184-187  link (scalar result broadcast to float4) ------------- */
+static inline float sd_link(f3 p, float le, float r1, float r2) {
+    f3 q = v3(p.x, fmaxf(fabsf(p.y) - le, 0.0f), p.z);
+    return len2(len2(q.x, q.y) - r1, q.z) - r2;
+}
+
+/* ---- cginc:189-192  cylinder (h acts as radius, r as half height) -------- */
+static inline float sd_cylinder(f3 p, float h, float r) {
+    float dx = fabsf(len2(p.x, p.z)) - h;
+    float dy = fabsf(p.y) - r;
+    return fminf(fmaxf(dx, dy), 0.0f) + len2(fmaxf(dx, 0.0f), fmaxf(dy, 0.0f));
+}
+
+/* ---- cginc:101-103  blend ------------------------------------------------ */
+static inline f3 blend3(f3 c1, f3 c2, float k) {
+    return scl3(normalize3(lerp3(c1, c2, k)), lerp1(len3(c1), len3(c2), k));
+}
+
+/* ---- cginc:110-113  smin(float4,float4,k) --------------------------------- */
+static inline f4 smin4(f4 a, f4 b, float k) {
+    float h = clamp1(0.5f + 0.5f * (b.w - a.w) / k, 0.0f, 1.0f);
+    f3 c = blend3(xyz(b), xyz(a), h);
+    f4 r = {c.x, c.y, c.z, lerp1(b.w, a.w, h) - k * h * (1.0f - h)};
+    return r;
+}
+
+/* primitive wrapper: p_i = rotate(p - pos, q);  o = prim(p_i / scale) * min(scale)
+ * (cginc:336-354) */
+static inline float prim_dist(const rmo_prim *pr, f3 p) {
+    f3 pos = v3(pr->pos[0], pr->pos[1], pr->pos[2]);
+    f4 q = {pr->quat[0], pr->quat[1], pr->quat[2], pr->quat[3]};
+    f3 s = v3(pr->scale[0], pr->scale[1], pr->scale[2]);
+    f3 pl = div3(rotate_q(sub3(p, pos), q), s);
+    float d;
+    switch (pr->type) {
+    case RMO_SPHERE:   d = sd_sphere(pl, pr->params[0]); break;
+    case RMO_BOX:      d = sd_box(pl, v3(pr->params[0], pr->params[1], pr->params[2])); break;
+    case RMO_LINK:     d = sd_link(pl, pr->params[0], pr->params[1], pr->params[2]); break;
+    case RMO_CYLINDER: d = sd_cylinder(pl, pr->params[0], pr->params[1]); break;
+    default:           d = sd_torus(pl, pr->params[0], pr->params[1]); break;
+    }
+    return d * min3(s);
+}
+
+/* the reference's fixed scene as a primitive table: sphere, box, link(5,5,.1),
+ * cylinder with colours (1,.25,.25) (.25,1,.25) (.25,.25,1) (1,1,.25)
+ * (cginc:351-359); positions/rotations/scales from the three matrices */
+static void legacy_prims(const rmo_uniforms *u, rmo_prim out[4]) {
+    static const float col[4][3] = {{1, .25f, .25f}, {.25f, 1, .25f}, {.25f, .25f, 1}, {1, 1, .25f}};
+    static const float par[4][4] = {{1, 0, 0, 0}, {1, 1, 1, 0}, {5, 5, .1f, 0}, {.5f, .5f, 0, 0}};
+    for (int i = 0; i < 4; i++) {
+        f4 p = mrow(u->positions, i), q = mrow(u->rotations, i), s = mrow(u->scales, i);
+        out[i].type = i;
+        out[i].op = RMO_OP_SMIN;
+        out[i].pos[0] = p.x; out[i].pos[1] = p.y; out[i].pos[2] = p.z;
+        out[i].quat[0] = q.x; out[i].quat[1] = q.y; out[i].quat[2] = q.z; out[i].quat[3] = q.w;
+        out[i].scale[0] = s.x; out[i].scale[1] = s.y; out[i].scale[2] = s.z;
+        memcpy(out[i].color, col[i], sizeof col[i]);
+        memcpy(out[i].params, par[i], sizeof par[i]);
+    }
+}
+
+typedef struct {
+    const rmo_uniforms *u;
+    const rmo_prim *prims;
+    int n;
+    rmo_prim legacy[4];
+    f3 ro, light;
+    f3 tl, tr, br, bl;     /* world-space corner rays */
+} scene_ctx;
+
+#define RMO_MAX_PRIMS 1024
+
+/* ---- cginc:334-364  scene(p): float4(rgb, distance) ----------------------
+ * For n == 4 this is literally smin(smin(o0,o1), smin(o2,o3)) (cginc:363).  For
+ * other n the same balanced pairwise tree is built level by level in index
+ * order; an odd element at the end of a level is carried up unchanged. */
+static inline f4 scene(const scene_ctx *c, f3 p) {
+    f4 o[RMO_MAX_PRIMS];
+    int n = c->n;
+    for (int i = 0; i < n; i++) {
+        const rmo_prim *pr = &c->prims[i];
+        o[i].w = prim_dist(pr, p);
+        o[i].x = pr->color[0]; o[i].y = pr->color[1]; o[i].z = pr->color[2];
+    }
+    float k = c->u->smooth_k;
+    while (n > 1) {
+        int m = 0;
+        for (int i = 0; i + 1 < n; i += 2) o[m++] = smin4(o[i], o[i + 1], k);
+        if (n & 1) o[m++] = o[n - 1];
+        n = m;
+    }
+    return o[0];
+}
+
+/* distance-only evaluation: exactly scene(p).w -- the .w lane of smin4 never
+ * reads rgb, so dropping the colour blend changes no bit of the result */
+static inline float scene_w(const scene_ctx *c, f3 p) {
+    float o[RMO_MAX_PRIMS];
+    int n = c->n;
+    for (int i = 0; i < n; i++) o[i] = prim_dist(&c->prims[i], p);
+    float k = c->u->smooth_k;
+    while (n > 1) {
+        int m = 0;
+        for (int i = 0; i + 1 < n; i += 2) {
+            float a = o[i], b = o[i + 1];
+            float h = clamp1(0.5f + 0.5f * (b - a) / k, 0.0f, 1.0f);
+            o[m++] = lerp1(b, a, h) - k * h * (1.0f - h);
+        }
+        if (n & 1) o[m++] = o[n - 1];
+        n = m;
+    }
+    return o[0];
+}
+
+typedef struct { int hit; int evals; float length; float contact; } march_t;
+
+/* ---- cginc:367-392  raymarch(ro, rd, depth, steps=2000) -------------------
+ * `hit` is read uninitialised in the reference when the loop never sets it;
+ * it is false here.  `contact` models the shader-global _ContactThreshold that
+ * the loop overwrites every iteration (cginc:376). */
+static inline march_t raymarch(const scene_ctx *c, f3 ro, f3 rd, float depth, float contact0) {
+    const rmo_uniforms *u = c->u;
+    depth = fminf(depth, u->max_dist);
+    float steps = fminf(2000.0f, u->max_steps);
+    float dm = 0.0f;
+    march_t r = {0, 0, 0.0f, contact0};
+    int i;
+    for (i = 0; (float)i < steps; i++) {
+        f3 cp = add3(ro, scl3(rd, dm));
+        float dts = scene_w(c, cp);
+        r.evals++;
+        dm += fabsf(dts) * u->step_factor;
+        r.contact = dm * .0025f;
+        if (fabsf(dts) < r.contact) { r.hit = 1; break; }
+        if (dm > depth) break;
+    }
+    r.length = dm;
+    return r;
+}
+
+/* ---- shader:50-68  getnormalraw(p, s=0): central differences, NOT divided -- */
+static inline f3 getnormalraw(const scene_ctx *c, f3 p) {
+    float e = fmaxf(0.0f, c->u->normal_sample_scale);
+    f3 ex = v3(e, 0, 0), ey = v3(0, e, 0), ez = v3(0, 0, e);
+    return v3(scene_w(c, add3(p, ex)) - scene_w(c, sub3(p, ex)),
+              scene_w(c, add3(p, ey)) - scene_w(c, sub3(p, ey)),
+              scene_w(c, add3(p, ez)) - scene_w(c, sub3(p, ez)));
+}
+
+/* ---- shader:102-123  getshadow(p, n, k=16, depth=2000, steps=2000) --------
+ * reads the contact threshold left behind by raymarch() (shader:107); the first
+ * iteration divides by dm == 0 (shader:111) */
+static inline float getshadow(const scene_ctx *c, f3 p, f3 n, float contact, int *evals) {
+    const rmo_uniforms *u = c->u;
+    const float k = 16.0f;
+    float depth = fminf(2000.0f, u->max_dist);
+    float steps = fminf(2000.0f, u->max_steps);
+    float dm = 0.0f, res = 1.0f;
+    p = add3(p, scl3(scl3(n, contact), 2.0f));
+    int i, ev = 0;
+    for (i = 0; (float)i < steps; i++) {
+        f3 cp = add3(p, scl3(c->light, dm));
+        float dts = scene_w(c, cp);
+        ev++;
+        res = fminf(res, k * dts / dm);
+        dm += fabsf(dts) * u->step_factor;
+        contact = dm * .0025f;
+        if (fabsf(dts) < contact) break;
+        if (dm > depth) break;
+    }
+    *evals = ev;
+    return res;
+}
+
+/* ---- shader:125-127  getAO ------------------------------------------------ */
+static inline float getAO(const scene_ctx *c, f3 n) {
+    float s = c->u->normal_sample_scale;
+    return clamp1(len3(v3(n.x / s, n.y / s, n.z / s)), 0.0f, 1.0f);
+}
+
+/* ---- cginc:26-33  vert: corner select ------------------------------------- */
+int rmo_vert_corner_index(float uvx, float uvy) {
+    return (int)(uvx + (uvx != 0.0f ? 1.0f - uvy : (1.0f - uvy) * 3.0f));
+}
+
+/* mul(_CameraInvViewMatrix, corner.xyz): float4x4 * float3 uses the upper-left
+ * 3x3 (cginc:31) */
+static inline f3 mul33(const float *m, f3 v) {
+    f4 r0 = mrow(m, 0), r1 = mrow(m, 1), r2 = mrow(m, 2);
+    return v3(dot3(xyz(r0), v), dot3(xyz(r1), v), dot3(xyz(r2), v));
+}
+
+static void scene_ctx_init(scene_ctx *c, const rmo_uniforms *u) {
+    c->u = u;
+    if (u->n_prims > 0) { c->prims = u->prims; c->n = u->n_prims; }
+    else { legacy_prims(u, c->legacy); c->prims = c->legacy; c->n = 4; }
+    c->ro = v3(u->cam_pos[0], u->cam_pos[1], u->cam_pos[2]);
+    c->light = v3(u->light[0], u->light[1], u->light[2]);   /* float4 -> float3 truncation */
+    c->tl = mul33(u->cam_inv_view, xyz(mrow(u->frustum_corners, 0)));
+    c->tr = mul33(u->cam_inv_view, xyz(mrow(u->frustum_corners, 1)));
+    c->br = mul33(u->cam_inv_view, xyz(mrow(u->frustum_corners, 2)));
+    c->bl = mul33(u->cam_inv_view, xyz(mrow(u->frustum_corners, 3)));
+}
+
+/* rasteriser interpolation of viewDir to the pixel centre, uv origin bottom-left:
+ * rd = lerp(lerp(BL,BR,u), lerp(TL,TR,u), v) */
+static inline f3 pixel_ray(const scene_ctx *c, int x, int y, int w, int h) {
+    float uu = ((float)x + 0.5f) / (float)w;
+    float vv = ((float)y + 0.5f) / (float)h;
+    return lerp3(lerp3(c->bl, c->br, uu), lerp3(c->tl, c->tr, uu), vv);
+}
+
+static inline uint8_t unorm8(float x) {
+    x = fminf(fmaxf(x, 0.0f), 1.0f);      /* saturate; NaN -> 0 */
+    return (uint8_t)floorf(x * 255.0f + 0.5f);
+}
+
+typedef struct {
+    scene_ctx sc;
+    const uint8_t *src; const float *sdepth;
+    uint8_t *rgba; float *depth; uint8_t *hit; float *rgbf; uint16_t *sp, *ss;
+    int w, h, y0, y1;
+    int mode;                 /* 0 frag, 1 perspective depth, 2 directional depth */
+    f3 dc[4]; f3 dfwd;        /* directional pass: corners TL,TR,BR,BL and forward */
+    atomic_int next_row;
+    pthread_mutex_t mu;
+    rmo_stats st;
+} job_t;
+
+/* ---- shader:149-216  frag -------------------------------------------------- */
+static void frag_pixel(job_t *j, int x, int y, rmo_stats *st) {
+    const scene_ctx *c = &j->sc;
+    const rmo_uniforms *u = c->u;
+    size_t idx = (size_t)y * (size_t)j->w + (size_t)x;
+
+    f3 tex;
+    if (j->src) tex = v3(j->src[idx * 4] / 255.0f, j->src[idx * 4 + 1] / 255.0f, j->src[idx * 4 + 2] / 255.0f);
+    else tex = v3(u->background[0], u->background[1], u->background[2]);
+    float depth = j->sdepth ? j->sdepth[idx] : u->far_plane;          /* shader:154 */
+
+    f3 ro = c->ro;
+    f3 rd = pixel_ray(c, x, y, j->w, j->h);
+    march_t r = raymarch(c, ro, rd, depth, u->contact_threshold);     /* shader:171 */
+    st->sum_steps_p += (uint64_t)r.evals;
+
+    f3 col = tex;
+    int sev = 0;
+    if (r.hit || u->shade_miss_pixels) {
+        f3 hitpoint = add3(ro, scl3(rd, r.length));                   /* shader:174 */
+        f3 rawnormal = getnormalraw(c, hitpoint);
+        f3 normal = normalize3(rawnormal);
+        f4 s = scene(c, hitpoint);                                    /* shader:193 */
+        f3 srgb = xyz(s);
+        float shadow = remap(getshadow(c, hitpoint, normal, r.contact, &sev), 0.0f, 1.0f, .25f, 1.0f);
+        float ndl = dot3(normal, c->light) * .5f + .5f;
+        f3 shaded = scl3(scl3(scl3(srgb, ndl), shadow), getAO(c, rawnormal));
+        st->sum_steps_s_all += (uint64_t)sev;
+        if (r.hit) { col = shaded; st->sum_steps_s += (uint64_t)sev; st->n_hit++; }
+    }
+    if (j->rgba) {
+        j->rgba[idx * 4 + 0] = unorm8(col.x);
+        j->rgba[idx * 4 + 1] = unorm8(col.y);
+        j->rgba[idx * 4 + 2] = unorm8(col.z);
+        j->rgba[idx * 4 + 3] = 255;                                   /* fixed4(col, 1) */
+    }
+    if (j->rgbf) { j->rgbf[idx * 3] = col.x; j->rgbf[idx * 3 + 1] = col.y; j->rgbf[idx * 3 + 2] = col.z; }
+    if (j->depth) j->depth[idx] = r.length;
+    if (j->hit) j->hit[idx] = (uint8_t)r.hit;
+    if (j->sp) j->sp[idx] = (uint16_t)r.evals;
+    if (j->ss) j->ss[idx] = (uint16_t)(r.hit ? sev : 0);
+}
+
+static void depth_pixel(job_t *j, int x, int y, rmo_stats *st) {
+    const scene_ctx *c = &j->sc;
+    size_t idx = (size_t)y * (size_t)j->w + (size_t)x;
+    f3 ro, rd;
+    if (j->mode == 1) {
+        ro = c->ro;
+        rd = pixel_ray(c, x, y, j->w, j->h);
+    } else {
+        float uu = ((float)x + 0.5f) / (float)j->w;
+        float vv = ((float)y + 0.5f) / (float)j->h;
+        ro = lerp3(lerp3(j->dc[3], j->dc[2], uu), lerp3(j->dc[0], j->dc[1], uu), vv);
+        rd = j->dfwd;
+    }
+    march_t r = raymarch(c, ro, rd, c->u->far_plane, c->u->contact_threshold);
+    st->sum_steps_p += (uint64_t)r.evals;
+    st->n_hit += (uint64_t)r.hit;
+    if (j->depth) j->depth[idx] = r.length;
+    if (j->hit) j->hit[idx] = (uint8_t)r.hit;
+}
+
+static void *worker(void *arg) {
+    job_t *j = (job_t *)arg;
+    rmo_stats st;
+    memset(&st, 0, sizeof st);
+    for (;;) {
+        int y = atomic_fetch_add(&j->next_row, 1);
+        if (y >= j->y1) break;
+        for (int x = 0; x < j->w; x++) {
+            if (j->mode == 0) frag_pixel(j, x, y, &st); else depth_pixel(j, x, y, &st);
+            st.n_pixels++;
+        }
+    }
+    pthread_mutex_lock(&j->mu);
+    j->st.n_pixels += st.n_pixels; j->st.n_hit += st.n_hit;
+    j->st.sum_steps_p += st.sum_steps_p; j->st.sum_steps_s += st.sum_steps_s;
+    j->st.sum_steps_s_all += st.sum_steps_s_all;
+    pthread_mutex_unlock(&j->mu);
+    return NULL;
+}
+
+int rmo_online_cpus(void) {
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { int n = CPU_COUNT(&set); if (n > 0) return n; }
+    long n = sysconf(_SC_NPROCESSORS_ONLN);
+    return n > 0 ? (int)n : 1;
+}
+
+static int run_job(job_t *j, int threads, rmo_stats *stats) {
+    if (j->sc.n > RMO_MAX_PRIMS || j->w <= 0 || j->h <= 0 || j->y0 < 0 || j->y1 > j->h) return -1;
+    if (threads <= 0) threads = rmo_online_cpus();
+    if (threads > 256) threads = 256;
+    int rows = j->y1 - j->y0;
+    if (threads > rows) threads = rows > 0 ? rows : 1;
+    atomic_init(&j->next_row, j->y0);
+    pthread_mutex_init(&j->mu, NULL);
+    memset(&j->st, 0, sizeof j->st);
+    pthread_t th[256];
+    int started = 0;
+    for (int t = 1; t < threads; t++)
+        if (pthread_create(&th[started], NULL, worker, j) == 0) started++;
+    worker(j);
+    for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+    pthread_mutex_destroy(&j->mu);
+    if (stats) *stats = j->st;
+    return 0;
+}
+
+int rmo_render(const rmo_uniforms *u, const uint8_t *src_rgba8, const float *scene_depth,
+               uint8_t *dst_rgba8, float *dst_depth, uint8_t *dst_hit, float *dst_rgb_f32,
+               uint16_t *dst_steps_p, uint16_t *dst_steps_s,
+               int w, int h, int y0, int y1, int threads, rmo_stats *stats) {
+    job_t *j = (job_t *)calloc(1, sizeof *j);
+    if (!j) return -2;
+    scene_ctx_init(&j->sc, u);
+    j->src = src_rgba8; j->sdepth = scene_depth;
+    j->rgba = dst_rgba8; j->depth = dst_depth; j->hit = dst_hit; j->rgbf = dst_rgb_f32;
+    j->sp = dst_steps_p; j->ss = dst_steps_s;
+    j->w = w; j->h = h; j->y0 = y0; j->y1 = y1; j->mode = 0;
+    int rc = run_job(j, threads, stats);
+    free(j);
+    return rc;
+}
+
+/* Depth pass from a perspective shadow camera.  The reference's ShadowMap
+ * fragment is a colour-inverting stub (Assets/ShadowMap.shader:20-25), so no
+ * reference arithmetic exists beyond the bindings ShadowMap.Render() makes
+ * (Assets/ShadowMap.cs:50-56): this pass is raymarch() along the rays those two
+ * matrices define, writing r.length. */
+int rmo_shadowmap_perspective(const rmo_uniforms *u, float *dst_depth, uint8_t *dst_hit,
+                              int w, int h, int threads, rmo_stats *stats) {
+    job_t *j = (job_t *)calloc(1, sizeof *j);
+    if (!j) return -2;
+    scene_ctx_init(&j->sc, u);
+    j->depth = dst_depth; j->hit = dst_hit;
+    j->w = w; j->h = h; j->y0 = 0; j->y1 = h; j->mode = 1;
+    int rc = run_job(j, threads, stats);
+    free(j);
+    return rc;
+}
+
+/* Orthographic depth pass over the rectangle ShadowMapDirectional.Update()
+ * computes (Assets/ShadowMapDirectional.cs:25-34, corner order TL,TR,BR,BL as
+ * its initialCorners :11-16): origin bilinear over the corners, direction =
+ * the transform's forward, marched with raymarch(). */
+int rmo_shadowmap_directional(const rmo_uniforms *u, const float corners[12], const float forward[3],
+                              float *dst_depth, uint8_t *dst_hit,
+                              int w, int h, int threads, rmo_stats *stats) {
+    job_t *j = (job_t *)calloc(1, sizeof *j);
+    if (!j) return -2;
+    scene_ctx_init(&j->sc, u);
+    for (int i = 0; i < 4; i++) j->dc[i] = v3(corners[i * 3], corners[i * 3 + 1], corners[i * 3 + 2]);
+    j->dfwd = v3(forward[0], forward[1], forward[2]);
+    j->depth = dst_depth; j->hit = dst_hit;
+    j->w = w; j->h = h; j->y0 = 0; j->y1 = h; j->mode = 2;
+    int rc = run_job(j, threads, stats);
+    free(j);
+    return rc;
+}
+
+/* ---- probes for the known-answer tests ------------------------------------- */
+float rmo_sphere(const float p[3], float r) { return sd_sphere(v3(p[0], p[1], p[2]), r); }
+float rmo_box(const float p[3], const float b[3]) { return sd_box(v3(p[0], p[1], p[2]), v3(b[0], b[1], b[2])); }
+float rmo_link(const float p[3], float le, float r1, float r2) { return sd_link(v3(p[0], p[1], p[2]), le, r1, r2); }
+float rmo_cylinder(const float p[3], float h, float r) { return sd_cylinder(v3(p[0], p[1], p[2]), h, r); }
+float rmo_torus(const float p[3], float tx, float ty) { return sd_torus(v3(p[0], p[1], p[2]), tx, ty); }
+void rmo_rotate_q(const float v[3], const float q[4], float out[3]) {
+    f4 qq = {q[0], q[1], q[2], q[3]};
+    f3 r = rotate_q(v3(v[0], v[1], v[2]), qq);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+float rmo_remap(float x, float o1, float o2, float n1, float n2) { return remap(x, o1, o2, n1, n2); }
+void rmo_smin4(const float a[4], const float b[4], float k, float out[4]) {
+    f4 aa = {a[0], a[1], a[2], a[3]}, bb = {b[0], b[1], b[2], b[3]};
+    f4 r = smin4(aa, bb, k);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+void rmo_scene(const rmo_uniforms *u, const float p[3], float out[4]) {
+    scene_ctx c;
+    scene_ctx_init(&c, u);
+    f4 r = scene(&c, v3(p[0], p[1], p[2]));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+void rmo_pixel_ray(const rmo_uniforms *u, int x, int y, int w, int h, float rd[3]) {
+    scene_ctx c;
+    scene_ctx_init(&c, u);
+    f3 r = pixel_ray(&c, x, y, w, h);
+    rd[0] = r.x; rd[1] = r.y; rd[2] = r.z;
+}
+int rmo_raymarch(const rmo_uniforms *u, const float ro[3], const float rd[3], float depth,
+                 float *length, int *evals) {
+    scene_ctx c;
+    scene_ctx_init(&c, u);
+    march_t r = raymarch(&c, v3(ro[0], ro[1], ro[2]), v3(rd[0], rd[1], rd[2]), depth, u->contact_threshold);
+    if (length) *length = r.length;
+    if (evals) *evals = r.evals;
+    return r.hit;
+}

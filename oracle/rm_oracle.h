@@ -1,0 +1,117 @@
+/*
+ * rm_oracle.h -- CPU oracle for the sphere-tracing path of symbiosinx/Raymarching.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the checker that the HIP path is compared
+ * against; nothing in the shipped library links, loads or calls it.  Only the
+ * test-suite, the smoke check and the benchmark's CPU-baseline leg may use it.
+ *
+ * PARITY UNPINNED BY THE REFERENCE: the reference holds no golden images, tests
+ * or known-answer vectors and only runs inside the Unity editor, so this oracle
+ * is pinned by (1) closed-form known-answer tests derived from the SDF formulas
+ * and (2) an independently written NumPy float32 restatement that must agree
+ * with it (tests/test_oracle_nversion.py).
+ *
+ * Arithmetic is strict IEEE-754 binary32: build with -ffp-contract=off and
+ * without -ffast-math.  HLSL intrinsics are expanded in ONE canonical way:
+ *   dot3(a,b)     = a.x*b.x + a.y*b.y + a.z*b.z            (left to right)
+ *   length(v)     = sqrt(dot(v,v))
+ *   normalize(v)  = v * (1/sqrt(dot(v,v)))
+ *   lerp(a,b,t)   = a + t*(b-a)
+ *   clamp(x,l,h)  = min(max(x,l),h)
+ *   min/max       = IEEE minNum/maxNum (a NaN operand is dropped)
+ */
+#ifndef RM_ORACLE_H
+#define RM_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* primitive kinds, in the order scene() uses them (Assets/Raymarching.cginc:351-354) */
+enum { RMO_SPHERE = 0, RMO_BOX = 1, RMO_LINK = 2, RMO_CYLINDER = 3, RMO_TORUS = 4 };
+/* combine operator applied when a primitive's subtree is merged upwards */
+enum { RMO_OP_SMIN = 0, RMO_OP_SMAX = 1 };
+
+typedef struct {
+    int32_t type;       /* RMO_* */
+    int32_t op;         /* RMO_OP_* (reserved; smooth union only for now) */
+    float   pos[3];     /* _Positions row   (Assets/Raymarching.cs:61) */
+    float   quat[4];    /* _Rotations row x,y,z,w (Assets/Raymarching.cs:71) */
+    float   scale[3];   /* _Scales row      (Assets/Raymarching.cs:79) */
+    float   color[3];   /* rgb assigned after the primitive call (cginc:356-359) */
+    float   params[4];  /* sphere: r | box: b.xyz | link: le,r1,r2 | cylinder: h,r | torus: t.x,t.y */
+} rmo_prim;
+
+typedef struct {
+    /* matrices are column-major float[16] exactly as a Unity Matrix4x4 is laid
+     * out; row i = {m[i], m[i+4], m[i+8], m[i+12]} */
+    float frustum_corners[16];   /* _FrustrumCorners   rows TL,TR,BR,BL (Raymarching.cs:50-53) */
+    float cam_inv_view[16];      /* _CameraInvViewMatrix (Raymarching.cs:87) */
+    float positions[16];         /* _Positions */
+    float rotations[16];         /* _Rotations */
+    float scales[16];            /* _Scales */
+    float cam_pos[3];            /* _WorldSpaceCameraPos (Raymarching.shader:167) */
+    float light[4];              /* _WorldSpaceLightPos0 (Raymarching.shader:109,199) */
+    float max_steps;             /* _MaxSteps */
+    float max_dist;              /* _MaxDist */
+    float step_factor;           /* _StepFactor */
+    float contact_threshold;     /* _ContactThreshold (initial value; overwritten by the march) */
+    float normal_sample_scale;   /* _NormalSampleScale */
+    float far_plane;             /* _ProjectionParams.z */
+    float smooth_k;              /* k of smin; the reference hard-codes the default .5 (cginc:110) */
+    float background[4];         /* constant _MainTex colour in [0,1] used when src == NULL */
+    int32_t n_prims;             /* 0: the reference's fixed 4-primitive scene from the matrices */
+    const rmo_prim *prims;       /* n_prims entries when n_prims > 0 */
+    int32_t shade_miss_pixels;   /* 1: run normal+shadow on miss pixels too, as the shader does
+                                    (their result is discarded by the select at shader:197-202) */
+} rmo_uniforms;
+
+typedef struct {
+    uint64_t n_pixels;
+    uint64_t n_hit;          /* pixels with r.hit                                    */
+    uint64_t sum_steps_p;    /* scene() evaluations in the primary march, all pixels */
+    uint64_t sum_steps_s;    /* scene() evaluations in the shadow march, hit pixels  */
+    uint64_t sum_steps_s_all;/* ... including miss pixels when shade_miss_pixels     */
+} rmo_stats;
+
+/* Renders rows [y0,y1) of a w x h frame.  Row 0 is the BOTTOM row (uv origin
+ * bottom-left, cginc:30).  All output pointers address full-frame buffers and may
+ * be NULL individually.  src_rgba8/scene_depth may be NULL (constant background /
+ * far plane everywhere).  threads <= 0 selects one thread per online CPU. */
+int rmo_render(const rmo_uniforms *u,
+               const uint8_t *src_rgba8, const float *scene_depth,
+               uint8_t *dst_rgba8, float *dst_depth, uint8_t *dst_hit,
+               float *dst_rgb_f32,            /* 3 floats/pixel, unquantised colour */
+               uint16_t *dst_steps_p, uint16_t *dst_steps_s,
+               int w, int h, int y0, int y1, int threads, rmo_stats *stats);
+
+/* depth-only passes (raymarch() only; length written, hit optional) */
+int rmo_shadowmap_perspective(const rmo_uniforms *u, float *dst_depth, uint8_t *dst_hit,
+                              int w, int h, int threads, rmo_stats *stats);
+int rmo_shadowmap_directional(const rmo_uniforms *u, const float corners[12], const float forward[3],
+                              float *dst_depth, uint8_t *dst_hit,
+                              int w, int h, int threads, rmo_stats *stats);
+
+/* single-function probes for the known-answer tests */
+float rmo_sphere(const float p[3], float r);
+float rmo_box(const float p[3], const float b[3]);
+float rmo_link(const float p[3], float le, float r1, float r2);
+float rmo_cylinder(const float p[3], float h, float r);
+float rmo_torus(const float p[3], float tx, float ty);
+void  rmo_rotate_q(const float v[3], const float q[4], float out[3]);
+float rmo_remap(float x, float o1, float o2, float n1, float n2);
+void  rmo_smin4(const float a[4], const float b[4], float k, float out[4]);
+void  rmo_scene(const rmo_uniforms *u, const float p[3], float out[4]);
+void  rmo_pixel_ray(const rmo_uniforms *u, int x, int y, int w, int h, float rd[3]);
+int   rmo_vert_corner_index(float uvx, float uvy);
+/* raymarch() from an arbitrary origin/direction: returns hit, writes length and eval count */
+int   rmo_raymarch(const rmo_uniforms *u, const float ro[3], const float rd[3], float depth,
+                   float *length, int *evals);
+int   rmo_online_cpus(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,587 @@
+// rm_api.cpp -- the C ABI of librmhip.so (include/rmhip.h): a Unity-Material-like
+// property bag per context, and blit entry points that turn the bag into one
+// kernel-argument block and launch the march.
+//
+// Compiled with -ffp-contract=off: the uniform-only sub-expressions evaluated
+// here (corner rays, quaternion terms, min(scale)) must round as the shader's
+// own fp32 evaluation would.
+#include "../../include/rmhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <array>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "rm_device.h"
+#include "rm_launch.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+const char *const kDeclared[] = {
+    // Assets/Raymarching.cginc:1-13
+    "_FrustrumCorners", "_CameraInvViewMatrix", "_MaxSteps", "_MaxDist", "_StepFactor", "_ContactThreshold",
+    "_Positions", "_Rotations", "_Scales", "_FractalScale", "_FractalRotationX", "_FractalRotationY",
+    "_FractalRotationZ",
+    // Assets/Raymarching.shader:3-18,30-46
+    "_MainTex", "_LightPosition", "_NormalSampleScale", "_Reflections", "_RefractiveIndex", "_Color1", "_Color2",
+    "_Glossiness", "_Skybox", "_CameraDepthTexture", "_ShadowMap", "_ShadowMapVPMatrix",
+    // Unity built-ins the shader reads, explicit here
+    "_WorldSpaceCameraPos", "_WorldSpaceLightPos0", "_ProjectionParams",
+    // stands in for _MainTex when no source image is passed
+    "_BackgroundColor",
+};
+
+typedef std::array<float, 4> vec4;
+typedef std::array<float, 16> mat4;
+
+}  // namespace
+
+struct rm_ctx {
+    int device = 0;
+    bool dev_ready = false;
+    std::string err;
+    std::map<std::string, float> floats;
+    std::map<std::string, vec4> vectors;
+    std::map<std::string, mat4> matrices;
+    std::vector<rm_primitive> prims;
+    bool prims_dirty = false;
+    int kernel = RM_KERNEL_AUTO;
+
+    hipStream_t stream = nullptr;           // used by the host-pointer entry points
+    unsigned long long *d_stats = nullptr;  // 4 counters
+    RmPrimDev *d_prims = nullptr;  size_t d_prims_cap = 0;
+    RmView *d_views = nullptr;     size_t d_views_cap = 0;
+    void *d_stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // src, sdepth, rgba, depth, hit
+    size_t d_stage_cap[5] = {0, 0, 0, 0, 0};
+
+    hipStream_t last_stream = nullptr;
+    uint64_t last_pixels = 0;
+    bool have_last = false;
+};
+
+namespace {
+
+int fail(rm_ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define RM_HIP(c, expr)                                                                       \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail((c), RM_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+mat4 mat_identity() {
+    mat4 m{};
+    m[0] = m[5] = m[10] = m[15] = 1.0f;
+    return m;
+}
+void set_row(mat4 &m, int i, float x, float y, float z, float w) { m[i] = x; m[i + 4] = y; m[i + 8] = z; m[i + 12] = w; }
+void get_row(const mat4 &m, int i, float r[4]) { r[0] = m[i]; r[1] = m[i + 4]; r[2] = m[i + 8]; r[3] = m[i + 12]; }
+
+// GetFrustumCorners() for a given vertical fov and aspect (Assets/Raymarching.cs:32-56)
+mat4 frustum_corners(float fov_deg, float aspect) {
+    const float deg2rad = 0.0174532924f;
+    float half = fov_deg * 0.5f;
+    float t = (float)std::tan((double)(half * deg2rad));
+    float a = t * aspect;
+    mat4 m = mat_identity();
+    set_row(m, 0, -a, t, -1.0f, 0.0f);
+    set_row(m, 1, a, t, -1.0f, 0.0f);
+    set_row(m, 2, a, -t, -1.0f, 0.0f);
+    set_row(m, 3, -a, -t, -1.0f, 0.0f);
+    return m;
+}
+
+// Values serialized in Assets/Raymarching.mat:62-105 and the objects of
+// Assets/Scenes/SampleScene.unity (camera :182-222, "Position N" transforms
+// :138-140,359-361,389-391,488-490, Directional Light :458).
+void load_defaults(rm_ctx *c) {
+    c->floats["_ContactThreshold"] = 0.002f;
+    c->floats["_FractalRotationX"] = 0.19f;
+    c->floats["_FractalRotationY"] = -0.26f;
+    c->floats["_FractalRotationZ"] = 0.14f;
+    c->floats["_FractalScale"] = 2.0f;
+    c->floats["_Glossiness"] = 0.2f;
+    c->floats["_MaxDist"] = 50.0f;
+    c->floats["_MaxSteps"] = 400.0f;
+    c->floats["_NormalSampleScale"] = 0.00005f;
+    c->floats["_Reflections"] = 3.12f;
+    c->floats["_RefractiveIndex"] = 1.0f;
+    c->floats["_StepFactor"] = 0.7f;
+    c->vectors["_Color1"] = {1, 1, 1, 1};
+    c->vectors["_Color2"] = {0.75f, 0.5f, 1, 1};
+    c->vectors["_LightPosition"] = {0, 0, 0, 0};
+    c->vectors["_WorldSpaceCameraPos"] = {2.0f, 1.0f, -11.01f, 0.0f};
+    c->vectors["_WorldSpaceLightPos0"] = {0.0f, 0.5f, 0.8660254f, 0.0f};
+    c->vectors["_ProjectionParams"] = {1.0f, 0.3f, 1000.0f, 1.0f / 1000.0f};
+    c->vectors["_BackgroundColor"] = {0.19215687f, 0.3019608f, 0.4745098f, 1.0f};
+    c->matrices["_FrustrumCorners"] = frustum_corners(80.0f, 16.0f / 9.0f);
+    mat4 c2w = mat_identity();                     // TRS(pos, identity, 1) * diag(1,1,-1,1)
+    set_row(c2w, 0, 1, 0, 0, 2.0f);
+    set_row(c2w, 1, 0, 1, 0, 1.0f);
+    set_row(c2w, 2, 0, 0, -1, -11.01f);
+    c->matrices["_CameraInvViewMatrix"] = c2w;
+    mat4 pos = mat_identity(), rot = mat_identity(), scl = mat_identity();
+    set_row(pos, 0, -0.584f, 0.049f, 0.602f, 0);
+    set_row(pos, 1, -0.74f, 0.929f, 0.0f, 0);
+    set_row(pos, 2, -7.87f, 0.0f, 1.522f, 0);
+    set_row(pos, 3, -3.074f, -0.087f, 0.08f, 0);
+    for (int i = 0; i < 4; i++) { set_row(rot, i, 0, 0, 0, 1); set_row(scl, i, 1, 1, 1, 0); }
+    c->matrices["_Positions"] = pos;
+    c->matrices["_Rotations"] = rot;
+    c->matrices["_Scales"] = scl;
+}
+
+float getf(rm_ctx *c, const char *n, float dflt) {
+    auto it = c->floats.find(n);
+    return it == c->floats.end() ? dflt : it->second;
+}
+vec4 getv(rm_ctx *c, const char *n) {
+    auto it = c->vectors.find(n);
+    return it == c->vectors.end() ? vec4{0, 0, 0, 0} : it->second;
+}
+mat4 getm(rm_ctx *c, const char *n) {
+    auto it = c->matrices.find(n);
+    return it == c->matrices.end() ? mat_identity() : it->second;
+}
+
+bool is_pow2(float s) {
+    if (!(s > 0.0f) || !std::isfinite(s)) return false;
+    int e;
+    float m = std::frexp(s, &e);
+    return m == 0.5f && e > -100 && e < 100;
+}
+
+uint32_t unorm8(float x) {
+    x = std::fmin(std::fmax(x, 0.0f), 1.0f);
+    return (uint32_t)std::floor(x * 255.0f + 0.5f);
+}
+
+// evaluates the uniform-only parts of the scene() wrapper (cginc:62-66,336-354)
+RmPrimDev prepare_prim(const rm_primitive &p) {
+    RmPrimDev d;
+    std::memset(&d, 0, sizeof d);
+    d.px = p.pos[0]; d.py = p.pos[1]; d.pz = p.pos[2];
+    d.ux = -p.quat[0]; d.uy = -p.quat[1]; d.uz = -p.quat[2];
+    float qw = p.quat[3];
+    d.c = qw * qw - (d.ux * d.ux + d.uy * d.uy + d.uz * d.uz);
+    d.w2 = 2.0f * qw;
+    d.ms = std::fmin(p.scale[0], std::fmin(p.scale[1], p.scale[2]));
+    d.type = p.type;
+    d.cr = p.color[0]; d.cg = p.color[1]; d.cb = p.color[2];
+    switch (p.type) {
+    case RM_SPHERE: d.a0 = p.params[0] * .5f; break;
+    case RM_BOX:    d.a0 = p.params[0] * .5f; d.a1 = p.params[1] * .5f; d.a2 = p.params[2] * .5f; break;
+    default:        d.a0 = p.params[0]; d.a1 = p.params[1]; d.a2 = p.params[2]; d.a3 = p.params[3]; break;
+    }
+    int flags = 0;
+    if (p.quat[0] == 0.0f && p.quat[1] == 0.0f && p.quat[2] == 0.0f && p.quat[3] == 1.0f) flags |= RM_PF_IDENT_ROT;
+    if (p.scale[0] == 1.0f && p.scale[1] == 1.0f && p.scale[2] == 1.0f) flags |= RM_PF_UNIT_SCALE;
+    if (is_pow2(p.scale[0]) && is_pow2(p.scale[1]) && is_pow2(p.scale[2])) flags |= RM_PF_RCP;
+    d.flags = flags;
+    d.sx = p.scale[0]; d.sy = p.scale[1]; d.sz = p.scale[2];
+    return d;
+}
+
+void legacy_prims(rm_ctx *c, rm_primitive out[4]) {
+    static const float col[4][3] = {{1, .25f, .25f}, {.25f, 1, .25f}, {.25f, .25f, 1}, {1, 1, .25f}};   // cginc:356-359
+    static const float par[4][4] = {{1, 0, 0, 0}, {1, 1, 1, 0}, {5, 5, .1f, 0}, {.5f, .5f, 0, 0}};     // cginc:351-354 defaults
+    mat4 P = getm(c, "_Positions"), R = getm(c, "_Rotations"), S = getm(c, "_Scales");
+    for (int i = 0; i < 4; i++) {
+        float p[4], q[4], s[4];
+        get_row(P, i, p); get_row(R, i, q); get_row(S, i, s);
+        out[i].type = i; out[i].op = 0;
+        std::memcpy(out[i].pos, p, 12);
+        std::memcpy(out[i].quat, q, 16);
+        std::memcpy(out[i].scale, s, 12);
+        std::memcpy(out[i].color, col[i], 12);
+        std::memcpy(out[i].params, par[i], 16);
+    }
+}
+
+// mul(_CameraInvViewMatrix, corner.xyz): float4x4 x float3 = upper-left 3x3 (cginc:31)
+void corner_world(const mat4 &c2w, const mat4 &fc, int row, float out[3]) {
+    float v[4];
+    get_row(fc, row, v);
+    for (int i = 0; i < 3; i++) {
+        float r[4];
+        get_row(c2w, i, r);
+        out[i] = r[0] * v[0] + r[1] * v[1] + r[2] * v[2];
+    }
+}
+
+void make_view(const mat4 &fc, const mat4 &c2w, const float cam_pos[3], RmView *v) {
+    std::memset(v, 0, sizeof *v);
+    v->ro[0] = cam_pos[0]; v->ro[1] = cam_pos[1]; v->ro[2] = cam_pos[2];
+    corner_world(c2w, fc, 0, v->tl);      // rows TL,TR,BR,BL (Assets/Raymarching.cs:50-53)
+    corner_world(c2w, fc, 1, v->tr);
+    corner_world(c2w, fc, 2, v->br);
+    corner_world(c2w, fc, 3, v->bl);
+}
+
+int ensure_device(rm_ctx *c) {
+    RM_HIP(c, hipSetDevice(c->device));
+    if (c->dev_ready) return RM_OK;
+    RM_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    RM_HIP(c, hipMalloc((void **)&c->d_stats, 4 * sizeof(unsigned long long)));
+    c->dev_ready = true;
+    return RM_OK;
+}
+
+template <class T>
+int ensure_cap(rm_ctx *c, T **ptr, size_t *cap, size_t bytes) {
+    if (bytes <= *cap) return RM_OK;
+    if (*ptr) { RM_HIP(c, hipFree(*ptr)); *ptr = nullptr; *cap = 0; }
+    RM_HIP(c, hipMalloc((void **)ptr, bytes));
+    *cap = bytes;
+    return RM_OK;
+}
+
+// Fills everything of RmParams that comes from the property bag.
+int build_params(rm_ctx *c, RmParams *U, hipStream_t stream) {
+    std::memset(U, 0, sizeof *U);
+    vec4 cam = getv(c, "_WorldSpaceCameraPos");
+    make_view(getm(c, "_FrustrumCorners"), getm(c, "_CameraInvViewMatrix"), cam.data(), &U->view);
+    vec4 L = getv(c, "_WorldSpaceLightPos0");
+    U->light[0] = L[0]; U->light[1] = L[1]; U->light[2] = L[2];          // float4 -> float3 (shader:109)
+    float max_steps = getf(c, "_MaxSteps", 100.0f);
+    float max_dist = getf(c, "_MaxDist", 100.0f);
+    U->steps = std::fmin(2000.0f, max_steps);
+    U->max_dist = max_dist;
+    U->shadow_depth = std::fmin(2000.0f, max_dist);
+    U->far_plane = getv(c, "_ProjectionParams")[2];
+    U->step_factor = getf(c, "_StepFactor", 1.0f);
+    U->nss_raw = getf(c, "_NormalSampleScale", 0.01f);
+    U->nss = std::fmax(0.0f, U->nss_raw);
+    vec4 bg = getv(c, "_BackgroundColor");
+    U->bg[0] = bg[0]; U->bg[1] = bg[1]; U->bg[2] = bg[2];
+    U->bg_rgba8 = unorm8(bg[0]) | (unorm8(bg[1]) << 8) | (unorm8(bg[2]) << 16) | 0xFF000000u;
+    U->band_rows = 1; U->part = 0; U->n_parts = 1;
+    U->n_poses = 1;
+    U->stats = c->d_stats;
+
+    int flags = RM_SF_IDENT_ROT | RM_SF_UNIT_SCALE | RM_SF_RCP;
+    if (c->prims.empty()) {
+        rm_primitive lp[4];
+        legacy_prims(c, lp);
+        for (int i = 0; i < 4; i++) {
+            U->prims4[i] = prepare_prim(lp[i]);
+            flags &= U->prims4[i].flags;
+        }
+        if ((flags & RM_SF_RCP) && !(flags & RM_SF_UNIT_SCALE))
+            for (int i = 0; i < 4; i++) {
+                U->prims4[i].sx = 1.0f / U->prims4[i].sx; U->prims4[i].sy = 1.0f / U->prims4[i].sy;
+                U->prims4[i].sz = 1.0f / U->prims4[i].sz;
+            }
+        U->n_prims = 0;
+    } else {
+        size_t n = c->prims.size();
+        std::vector<RmPrimDev> t(n);
+        for (size_t i = 0; i < n; i++) { t[i] = prepare_prim(c->prims[i]); flags &= t[i].flags; }
+        if ((flags & RM_SF_RCP) && !(flags & RM_SF_UNIT_SCALE))
+            for (size_t i = 0; i < n; i++) { t[i].sx = 1.0f / t[i].sx; t[i].sy = 1.0f / t[i].sy; t[i].sz = 1.0f / t[i].sz; }
+        if (c->prims_dirty || !c->d_prims) {
+            int rc = ensure_cap(c, &c->d_prims, &c->d_prims_cap, n * sizeof(RmPrimDev));
+            if (rc) return rc;
+            // the table must be in place before any later launch reads it, and the
+            // host vector dies at return: a blocking copy, done only when the scene changed
+            RM_HIP(c, hipStreamSynchronize(stream));
+            RM_HIP(c, hipMemcpy(c->d_prims, t.data(), n * sizeof(RmPrimDev), hipMemcpyHostToDevice));
+            c->prims_dirty = false;
+        }
+        U->prim_table = c->d_prims;
+        U->n_prims = (int)n;
+    }
+    U->scene_flags = flags;
+    return RM_OK;
+}
+
+int check_size(rm_ctx *c, int w, int h) {
+    if (w <= 0 || h <= 0) return fail(c, RM_E_ARG, "width and height must be positive");
+    if (w > 32768 || h > 32768) return fail(c, RM_E_RANGE, "frame larger than 32768 x 32768");
+    return RM_OK;
+}
+
+int launch(rm_ctx *c, const RmParams &U, hipStream_t stream) {
+    RM_HIP(c, hipMemsetAsync(c->d_stats, 0, 4 * sizeof(unsigned long long), stream));
+    RM_HIP(c, rm_launch_tiles(U, stream));
+    c->last_stream = stream;
+    c->last_pixels = (uint64_t)U.w * (uint64_t)U.rows * (uint64_t)U.n_poses;
+    c->have_last = true;
+    return RM_OK;
+}
+
+int stage(rm_ctx *c, int slot, size_t bytes) { return ensure_cap(c, &c->d_stage[slot], &c->d_stage_cap[slot], bytes); }
+
+}  // namespace
+
+extern "C" {
+
+const char *rm_version(void) { return "rmhip 0.1 (gfx950)"; }
+
+rm_ctx *rm_create(int hip_device) {
+    if (hip_device < 0) { g_create_error = "negative device index"; return nullptr; }
+    rm_ctx *c = new (std::nothrow) rm_ctx();
+    if (!c) { g_create_error = "out of memory"; return nullptr; }
+    c->device = hip_device;
+    load_defaults(c);
+    return c;
+}
+
+void rm_destroy(rm_ctx *c) {
+    if (!c) return;
+    if (c->dev_ready) {
+        (void)hipSetDevice(c->device);
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        if (c->last_stream) (void)hipStreamSynchronize(c->last_stream);
+        for (int i = 0; i < 5; i++) if (c->d_stage[i]) (void)hipFree(c->d_stage[i]);
+        if (c->d_prims) (void)hipFree(c->d_prims);
+        if (c->d_views) (void)hipFree(c->d_views);
+        if (c->d_stats) (void)hipFree(c->d_stats);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+    }
+    delete c;
+}
+
+const char *rm_last_error(rm_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int rm_set_float(rm_ctx *c, const char *name, float v) {
+    if (!c || !name) return fail(c, RM_E_ARG, "rm_set_float: null argument");
+    c->floats[name] = v;
+    return RM_OK;
+}
+int rm_set_int(rm_ctx *c, const char *name, int v) {
+    // Unity 2018 keeps SetInt values in the material's float table
+    if (!c || !name) return fail(c, RM_E_ARG, "rm_set_int: null argument");
+    c->floats[name] = (float)v;
+    return RM_OK;
+}
+int rm_set_vector(rm_ctx *c, const char *name, const float v[4]) {
+    if (!c || !name || !v) return fail(c, RM_E_ARG, "rm_set_vector: null argument");
+    c->vectors[name] = {v[0], v[1], v[2], v[3]};
+    return RM_OK;
+}
+int rm_set_matrix(rm_ctx *c, const char *name, const float m[16]) {
+    if (!c || !name || !m) return fail(c, RM_E_ARG, "rm_set_matrix: null argument");
+    mat4 a;
+    std::memcpy(a.data(), m, sizeof(float) * 16);
+    c->matrices[name] = a;
+    return RM_OK;
+}
+int rm_get_float(rm_ctx *c, const char *name, float *v) {
+    if (!c || !name || !v) return fail(c, RM_E_ARG, "rm_get_float: null argument");
+    auto it = c->floats.find(name);
+    if (it == c->floats.end()) return fail(c, RM_E_ARG, std::string("no float property ") + name);
+    *v = it->second;
+    return RM_OK;
+}
+int rm_get_int(rm_ctx *c, const char *name, int *v) {
+    float f;
+    if (!v) return fail(c, RM_E_ARG, "rm_get_int: null argument");
+    int rc = rm_get_float(c, name, &f);
+    if (rc == RM_OK) *v = (int)f;
+    return rc;
+}
+int rm_get_vector(rm_ctx *c, const char *name, float v[4]) {
+    if (!c || !name || !v) return fail(c, RM_E_ARG, "rm_get_vector: null argument");
+    auto it = c->vectors.find(name);
+    if (it == c->vectors.end()) return fail(c, RM_E_ARG, std::string("no vector property ") + name);
+    std::memcpy(v, it->second.data(), sizeof(float) * 4);
+    return RM_OK;
+}
+int rm_get_matrix(rm_ctx *c, const char *name, float m[16]) {
+    if (!c || !name || !m) return fail(c, RM_E_ARG, "rm_get_matrix: null argument");
+    auto it = c->matrices.find(name);
+    if (it == c->matrices.end()) return fail(c, RM_E_ARG, std::string("no matrix property ") + name);
+    std::memcpy(m, it->second.data(), sizeof(float) * 16);
+    return RM_OK;
+}
+int rm_has_property(rm_ctx *c, const char *name) {
+    if (!c || !name) return 0;
+    for (const char *d : kDeclared) if (std::strcmp(d, name) == 0) return 1;
+    return 0;
+}
+
+int rm_set_primitives(rm_ctx *c, const rm_primitive *prims, int n) {
+    if (!c || n < 0 || (n > 0 && !prims)) return fail(c, RM_E_ARG, "rm_set_primitives: bad argument");
+    if (n > RM_MAX_PRIMS) return fail(c, RM_E_RANGE, "more than RM_MAX_PRIMS primitives");
+    for (int i = 0; i < n; i++)
+        if (prims[i].type < RM_SPHERE || prims[i].type > RM_TORUS || prims[i].op != 0)
+            return fail(c, RM_E_ARG, "rm_set_primitives: unknown primitive type or operator");
+    c->prims.assign(prims, prims + n);
+    c->prims_dirty = true;
+    return RM_OK;
+}
+
+int rm_set_kernel(rm_ctx *c, int variant) {
+    if (!c) return RM_E_ARG;
+    if (variant != RM_KERNEL_AUTO && variant != RM_KERNEL_TILE) return fail(c, RM_E_ARG, "unknown kernel variant");
+    c->kernel = variant;
+    return RM_OK;
+}
+
+int rm_band_rows(int h, int band_rows, int part, int n_parts) {
+    if (h <= 0 || band_rows <= 0 || n_parts <= 0 || part < 0 || part >= n_parts) return RM_E_ARG;
+    int rows = 0;
+    int n_bands = (h + band_rows - 1) / band_rows;
+    for (int b = part; b < n_bands; b += n_parts) {
+        int y0 = b * band_rows, y1 = y0 + band_rows;
+        if (y1 > h) y1 = h;
+        rows += y1 - y0;
+    }
+    return rows;
+}
+
+int rm_blit_bands_device(rm_ctx *c, const void *d_src, const void *d_sdepth, void *d_rgba, void *d_depth, void *d_hit,
+                         int w, int h, int band_rows, int part, int n_parts, void *hip_stream) {
+    if (!c) return RM_E_ARG;
+    int rc = check_size(c, w, h);
+    if (rc) return rc;
+    int rows = rm_band_rows(h, band_rows, part, n_parts);
+    if (rows < 0) return fail(c, RM_E_ARG, "rm_blit_bands_device: bad band arguments");
+    if (rows == 0) return RM_OK;
+    if ((rc = ensure_device(c))) return rc;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    RmParams U;
+    if ((rc = build_params(c, &U, stream))) return rc;
+    U.w = w; U.h = h; U.rows = rows;
+    U.band_rows = band_rows; U.part = part; U.n_parts = n_parts;
+    U.mode = RM_MODE_FRAG;
+    U.src = (const uint8_t *)d_src; U.sdepth = (const float *)d_sdepth;
+    U.dst_rgba = (uint8_t *)d_rgba; U.dst_depth = (float *)d_depth; U.dst_hit = (uint8_t *)d_hit;
+    return launch(c, U, stream);
+}
+
+int rm_blit_device(rm_ctx *c, const void *d_src, const void *d_sdepth, void *d_rgba, void *d_depth, void *d_hit,
+                   int w, int h, void *hip_stream) {
+    if (!c) return RM_E_ARG;
+    return rm_blit_bands_device(c, d_src, d_sdepth, d_rgba, d_depth, d_hit, w, h, h > 0 ? h : 1, 0, 1, hip_stream);
+}
+
+int rm_blit_poses_device(rm_ctx *c, int n_poses, const float *fcs, const float *c2ws, const float *cam_pos,
+                         void *d_rgba, void *d_depth, void *d_hit, int w, int h, void *hip_stream) {
+    if (!c) return RM_E_ARG;
+    if (n_poses <= 0 || !fcs || !c2ws || !cam_pos) return fail(c, RM_E_ARG, "rm_blit_poses_device: bad argument");
+    if (n_poses > 65535) return fail(c, RM_E_RANGE, "more than 65535 poses in one call");
+    int rc = check_size(c, w, h);
+    if (rc) return rc;
+    if ((rc = ensure_device(c))) return rc;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    RmParams U;
+    if ((rc = build_params(c, &U, stream))) return rc;
+    std::vector<RmView> views((size_t)n_poses);
+    for (int i = 0; i < n_poses; i++) {
+        mat4 fc, c2w;
+        std::memcpy(fc.data(), fcs + (size_t)i * 16, 64);
+        std::memcpy(c2w.data(), c2ws + (size_t)i * 16, 64);
+        make_view(fc, c2w, cam_pos + (size_t)i * 3, &views[(size_t)i]);
+    }
+    if ((rc = ensure_cap(c, &c->d_views, &c->d_views_cap, views.size() * sizeof(RmView)))) return rc;
+    // earlier launches on this stream may still read the previous views
+    RM_HIP(c, hipStreamSynchronize(stream));
+    RM_HIP(c, hipMemcpy(c->d_views, views.data(), views.size() * sizeof(RmView), hipMemcpyHostToDevice));
+    U.views = c->d_views;
+    U.n_poses = n_poses;
+    U.w = w; U.h = h; U.rows = h; U.band_rows = h;
+    U.mode = RM_MODE_FRAG;
+    U.dst_rgba = (uint8_t *)d_rgba; U.dst_depth = (float *)d_depth; U.dst_hit = (uint8_t *)d_hit;
+    return launch(c, U, stream);
+}
+
+int rm_blit(rm_ctx *c, const uint8_t *src, const float *sdepth, uint8_t *rgba, float *depth, uint8_t *hit, int w, int h) {
+    if (!c) return RM_E_ARG;
+    int rc = check_size(c, w, h);
+    if (rc) return rc;
+    if ((rc = ensure_device(c))) return rc;
+    size_t n = (size_t)w * (size_t)h;
+    if (src)    { if ((rc = stage(c, 0, n * 4))) return rc; RM_HIP(c, hipMemcpyAsync(c->d_stage[0], src, n * 4, hipMemcpyHostToDevice, c->stream)); }
+    if (sdepth) { if ((rc = stage(c, 1, n * 4))) return rc; RM_HIP(c, hipMemcpyAsync(c->d_stage[1], sdepth, n * 4, hipMemcpyHostToDevice, c->stream)); }
+    if (rgba)  if ((rc = stage(c, 2, n * 4))) return rc;
+    if (depth) if ((rc = stage(c, 3, n * 4))) return rc;
+    if (hit)   if ((rc = stage(c, 4, n))) return rc;
+    rc = rm_blit_device(c, src ? c->d_stage[0] : nullptr, sdepth ? c->d_stage[1] : nullptr,
+                        rgba ? c->d_stage[2] : nullptr, depth ? c->d_stage[3] : nullptr, hit ? c->d_stage[4] : nullptr,
+                        w, h, c->stream);
+    if (rc) return rc;
+    if (rgba)  RM_HIP(c, hipMemcpyAsync(rgba, c->d_stage[2], n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (depth) RM_HIP(c, hipMemcpyAsync(depth, c->d_stage[3], n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (hit)   RM_HIP(c, hipMemcpyAsync(hit, c->d_stage[4], n, hipMemcpyDeviceToHost, c->stream));
+    RM_HIP(c, hipStreamSynchronize(c->stream));
+    return RM_OK;
+}
+
+static int depth_pass_device(rm_ctx *c, int mode, const float corners[12], const float forward[3],
+                             void *d_depth, void *d_hit, int w, int h, void *hip_stream) {
+    int rc = check_size(c, w, h);
+    if (rc) return rc;
+    if ((rc = ensure_device(c))) return rc;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    RmParams U;
+    if ((rc = build_params(c, &U, stream))) return rc;
+    U.w = w; U.h = h; U.rows = h; U.band_rows = h;
+    U.mode = mode;
+    if (mode == RM_MODE_DEPTH_ORTHO) {
+        std::memcpy(U.ortho_c, corners, sizeof(float) * 12);
+        std::memcpy(U.ortho_fwd, forward, sizeof(float) * 3);
+    }
+    U.dst_depth = (float *)d_depth; U.dst_hit = (uint8_t *)d_hit;
+    return launch(c, U, stream);
+}
+
+static int depth_pass_host(rm_ctx *c, int mode, const float corners[12], const float forward[3], float *depth, int w, int h) {
+    if (!depth) return fail(c, RM_E_ARG, "null destination");
+    int rc = check_size(c, w, h);
+    if (rc) return rc;
+    if ((rc = ensure_device(c))) return rc;
+    size_t n = (size_t)w * (size_t)h;
+    if ((rc = stage(c, 3, n * 4))) return rc;
+    if ((rc = depth_pass_device(c, mode, corners, forward, c->d_stage[3], nullptr, w, h, c->stream))) return rc;
+    RM_HIP(c, hipMemcpyAsync(depth, c->d_stage[3], n * 4, hipMemcpyDeviceToHost, c->stream));
+    RM_HIP(c, hipStreamSynchronize(c->stream));
+    return RM_OK;
+}
+
+int rm_shadowmap_render_device(rm_ctx *c, void *d_depth, void *d_hit, int w, int h, void *hip_stream) {
+    if (!c) return RM_E_ARG;
+    return depth_pass_device(c, RM_MODE_DEPTH_PERSP, nullptr, nullptr, d_depth, d_hit, w, h, hip_stream);
+}
+int rm_shadowmap_render(rm_ctx *c, float *depth, int w, int h) {
+    if (!c) return RM_E_ARG;
+    return depth_pass_host(c, RM_MODE_DEPTH_PERSP, nullptr, nullptr, depth, w, h);
+}
+int rm_shadowmap_directional_device(rm_ctx *c, const float corners[12], const float forward[3], void *d_depth,
+                                    void *d_hit, int w, int h, void *hip_stream) {
+    if (!c) return RM_E_ARG;
+    if (!corners || !forward) return fail(c, RM_E_ARG, "null corners/forward");
+    return depth_pass_device(c, RM_MODE_DEPTH_ORTHO, corners, forward, d_depth, d_hit, w, h, hip_stream);
+}
+int rm_shadowmap_directional(rm_ctx *c, const float corners[12], const float forward[3], float *depth, int w, int h) {
+    if (!c) return RM_E_ARG;
+    if (!corners || !forward) return fail(c, RM_E_ARG, "null corners/forward");
+    return depth_pass_host(c, RM_MODE_DEPTH_ORTHO, corners, forward, depth, w, h);
+}
+
+int rm_get_stats(rm_ctx *c, rm_stats *out) {
+    if (!c || !out) return fail(c, RM_E_ARG, "rm_get_stats: null argument");
+    if (!c->have_last) return fail(c, RM_E_ARG, "rm_get_stats: no blit has run");
+    RM_HIP(c, hipSetDevice(c->device));
+    RM_HIP(c, hipStreamSynchronize(c->last_stream));
+    unsigned long long v[4];
+    RM_HIP(c, hipMemcpy(v, c->d_stats, sizeof v, hipMemcpyDeviceToHost));
+    out->n_pixels = c->last_pixels;
+    out->n_hit = v[0];
+    out->sum_steps_p = v[1];
+    out->sum_steps_s = v[2];
+    return RM_OK;
+}
+
+}  // extern "C"

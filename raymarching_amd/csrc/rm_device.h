@@ -1,0 +1,80 @@
+// rm_device.h -- plain-data structs shared by the host side of librmhip and its
+// gfx950 kernels.  Everything the march needs per launch travels in RmParams as
+// a by-value kernel argument, so wave-uniform scene constants are read through
+// the scalar unit (constant cache -> SGPRs) rather than per lane.
+#pragma once
+#include <stdint.h>
+
+// One primitive with every uniform-only sub-expression of the reference's
+// scene() wrapper evaluated once on the host, in the same fp32 operation order
+// the shader would use (Assets/Raymarching.cginc:62-66, 336-354):
+//   u  = -q.xyz                      c  = q.w*q.w - dot(u,u)
+//   w2 = 2*q.w                       ms = min(scale.x, min(scale.y, scale.z))
+struct RmPrimDev {
+    float px, py, pz;      // _Positions row
+    float ux, uy, uz;      // -q.xyz
+    float c;               // q.w*q.w - dot(u,u)
+    float w2;              // 2*q.w
+    float sx, sy, sz;      // scale, or its reciprocal when RM_PF_RCP is set
+    float ms;              // min(scale)
+    float a0, a1, a2, a3;  // sphere: r*.5 | box: b*.5 | link: le,r1,r2 | cylinder: h,r | torus: t.x,t.y
+    float cr, cg, cb;      // colour assigned after the primitive call (cginc:356-359)
+    int32_t type;
+    int32_t flags;
+    int32_t pad[3];
+};
+static_assert(sizeof(RmPrimDev) == 96, "RmPrimDev layout");
+
+enum : int32_t {
+    RM_PF_IDENT_ROT  = 1,   // q == (0,0,0,1): rotate() returns its argument bit for bit
+    RM_PF_UNIT_SCALE = 2,   // scale == (1,1,1): p/scale == p, d*min(scale) == d
+    RM_PF_RCP        = 4,   // every scale component is a power of two: p/s == p*(1/s) exactly
+};
+
+// scene-wide specialisation, the AND of the per-primitive flags
+enum : int32_t {
+    RM_SF_IDENT_ROT  = 1,
+    RM_SF_UNIT_SCALE = 2,
+    RM_SF_RCP        = 4,
+};
+
+struct RmView {
+    float ro[3];           // _WorldSpaceCameraPos
+    float bl[3], br[3], tl[3], tr[3];   // world-space corner rays: mul((float3x3)_CameraInvViewMatrix, _FrustrumCorners[i].xyz)
+    float pad;
+};
+static_assert(sizeof(RmView) == 64, "RmView layout");
+
+enum : int32_t { RM_MODE_FRAG = 0, RM_MODE_DEPTH_PERSP = 1, RM_MODE_DEPTH_ORTHO = 2 };
+
+struct RmParams {
+    RmView   view;             // used when views == nullptr
+    float    light[3];         // _WorldSpaceLightPos0.xyz
+    float    steps;            // min(2000, _MaxSteps)          (cginc:369, shader:104)
+    float    max_dist;         // _MaxDist
+    float    shadow_depth;     // min(2000, _MaxDist)           (shader:103)
+    float    far_plane;        // _ProjectionParams.z
+    float    step_factor;      // _StepFactor
+    float    nss;              // max(0, _NormalSampleScale)    (shader:51)
+    float    nss_raw;          // _NormalSampleScale            (shader:126)
+    float    bg[3];            // constant _MainTex colour
+    uint32_t bg_rgba8;         // the same, quantised, alpha 255
+    float    ortho_c[4][3];    // directional pass: corners TL,TR,BR,BL
+    float    ortho_fwd[3];
+    int32_t  w, h;             // full frame size
+    int32_t  rows;             // rows rendered by this launch (compact output rows)
+    int32_t  band_rows, part, n_parts;
+    int32_t  mode;
+    int32_t  n_poses;
+    int32_t  n_prims;          // 0: prims4 below
+    int32_t  scene_flags;
+    const RmView    *views;    // n_poses views, or nullptr
+    const RmPrimDev *prim_table;
+    const uint8_t   *src;      // full-frame RGBA8 or nullptr
+    const float     *sdepth;   // full-frame linear eye depth or nullptr
+    uint8_t  *dst_rgba;
+    float    *dst_depth;
+    uint8_t  *dst_hit;
+    unsigned long long *stats; // [0] n_hit [1] sum primary evals [2] sum shadow evals
+    RmPrimDev prims4[4];
+};

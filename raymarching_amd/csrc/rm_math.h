@@ -1,0 +1,199 @@
+// rm_math.h -- device-side SDF arithmetic of the march, written for gfx950.
+//
+// Every expression keeps the operand order of the shader source it replaces and
+// the file is compiled with -ffp-contract=off, so each scene evaluation rounds
+// exactly as a strict binary32 evaluation of the reference would.  What is
+// changed is only what cannot change a bit of the result:
+//   * uniform-only sub-expressions arrive pre-evaluated in RmPrimDev,
+//   * the march loops evaluate the distance lane of smin() alone (its rgb lanes
+//     never feed .w, Assets/Raymarching.cginc:110-113),
+//   * k = .5 is a power of two, so 0.5*(b-a)/k == (b-a) and k*h == 0.5*h,
+//   * rotate() by the identity quaternion and a divide by a unit scale are
+//     skipped, a divide by a power-of-two scale is a multiply by its reciprocal.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rm_device.h"
+
+#define RM_DI __device__ __forceinline__
+
+struct V3 { float x, y, z; };
+struct V4 { float x, y, z, w; };
+
+RM_DI V3 mk3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+RM_DI float rm_dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RM_DI float rm_len3(V3 a) { return sqrtf(rm_dot3(a, a)); }
+RM_DI float rm_len2(float x, float y) { return sqrtf(x * x + y * y); }
+RM_DI float rm_lerp(float a, float b, float t) { return a + t * (b - a); }
+RM_DI V3 rm_lerp3(V3 a, V3 b, float t) { return mk3(rm_lerp(a.x, b.x, t), rm_lerp(a.y, b.y, t), rm_lerp(a.z, b.z, t)); }
+RM_DI float rm_clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+RM_DI V3 rm_normalize(V3 a) { float r = 1.0f / sqrtf(rm_dot3(a, a)); return mk3(a.x * r, a.y * r, a.z * r); }
+
+// scale handling chosen per scene on the host
+enum { RM_SCL_UNIT = 0, RM_SCL_RCP = 1, RM_SCL_DIV = 2 };
+
+// p_i = rotate(p - pos, q) / scale        (cginc:336-354, rotate at :62-66)
+template <bool ROT, int SCL>
+RM_DI V3 rm_to_local(const RmPrimDev &P, V3 p) {
+    V3 v = mk3(p.x - P.px, p.y - P.py, p.z - P.pz);
+    if (ROT) {
+        V3 u = mk3(P.ux, P.uy, P.uz);
+        float a = 2.0f * rm_dot3(u, v);
+        V3 cr = mk3(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x);
+        v = mk3((u.x * a + v.x * P.c) + cr.x * P.w2,
+                (u.y * a + v.y * P.c) + cr.y * P.w2,
+                (u.z * a + v.z * P.c) + cr.z * P.w2);
+    }
+    if (SCL == RM_SCL_RCP) v = mk3(v.x * P.sx, v.y * P.sy, v.z * P.sz);
+    if (SCL == RM_SCL_DIV) v = mk3(v.x / P.sx, v.y / P.sy, v.z / P.sz);
+    return v;
+}
+
+// cginc:169-171; a0 = r*.5
+RM_DI float rm_sphere(const RmPrimDev &P, V3 p) { return rm_len3(p) - P.a0; }
+// cginc:173-177; a0..a2 = b*.5
+RM_DI float rm_box(const RmPrimDev &P, V3 p) {
+    float dx = fabsf(p.x) - P.a0, dy = fabsf(p.y) - P.a1, dz = fabsf(p.z) - P.a2;
+    V3 m = mk3(fmaxf(dx, 0.0f), fmaxf(dy, 0.0f), fmaxf(dz, 0.0f));
+    return rm_len3(m) + fminf(fmaxf(dx, fmaxf(dy, dz)), 0.0f);
+}
+// cginc:184-187; a0 = le, a1 = r1, a2 = r2
+RM_DI float rm_link(const RmPrimDev &P, V3 p) {
+    float qy = fmaxf(fabsf(p.y) - P.a0, 0.0f);
+    return rm_len2(rm_len2(p.x, qy) - P.a1, p.z) - P.a2;
+}
+// cginc:189-192; a0 = h (radius), a1 = r (half height)
+RM_DI float rm_cylinder(const RmPrimDev &P, V3 p) {
+    float dx = fabsf(rm_len2(p.x, p.z)) - P.a0;
+    float dy = fabsf(p.y) - P.a1;
+    return fminf(fmaxf(dx, dy), 0.0f) + rm_len2(fmaxf(dx, 0.0f), fmaxf(dy, 0.0f));
+}
+// cginc:179-182; a0 = t.x, a1 = t.y
+RM_DI float rm_torus(const RmPrimDev &P, V3 p) {
+    return rm_len2(rm_len2(p.x, p.y) - P.a0, p.z) - P.a1;
+}
+
+// distance lane of smin(float4 a, float4 b, .5)  (cginc:110-113)
+RM_DI float rm_smin_h(float a, float b) { return rm_clamp01(0.5f + (b - a)); }
+RM_DI float rm_smin_w(float a, float b) {
+    float h = rm_smin_h(a, b);
+    return rm_lerp(b, a, h) - (0.5f * h) * (1.0f - h);
+}
+// full smin: rgb through blend() (cginc:101-103)
+RM_DI V4 rm_smin4(V4 a, V4 b) {
+    float h = rm_smin_h(a.w, b.w);
+    V3 c1 = mk3(b.x, b.y, b.z), c2 = mk3(a.x, a.y, a.z);
+    V3 n = rm_normalize(rm_lerp3(c1, c2, h));
+    float l = rm_lerp(rm_len3(c1), rm_len3(c2), h);
+    V4 r;
+    r.x = n.x * l; r.y = n.y * l; r.z = n.z * l;
+    r.w = rm_lerp(b.w, a.w, h) - (0.5f * h) * (1.0f - h);
+    return r;
+}
+
+template <bool ROT, int SCL>
+RM_DI float rm_prim_typed(const RmPrimDev &P, int type, V3 p) {
+    V3 l = rm_to_local<ROT, SCL>(P, p);
+    float d;
+    switch (type) {
+    case 0:  d = rm_sphere(P, l); break;
+    case 1:  d = rm_box(P, l); break;
+    case 2:  d = rm_link(P, l); break;
+    case 3:  d = rm_cylinder(P, l); break;
+    default: d = rm_torus(P, l); break;
+    }
+    return SCL == RM_SCL_UNIT ? d : d * P.ms;
+}
+
+// The reference's fixed scene: sphere, box, link, cylinder in slots 0..3
+// (cginc:351-354) combined as smin(smin(o0,o1), smin(o2,o3)) (cginc:363).
+template <bool ROT, int SCL>
+struct Scene4 {
+    const RmParams &U;
+    RM_DI explicit Scene4(const RmParams &u) : U(u) {}
+    RM_DI float w(V3 p) const {
+        float o0 = rm_prim_typed<ROT, SCL>(U.prims4[0], 0, p);
+        float o1 = rm_prim_typed<ROT, SCL>(U.prims4[1], 1, p);
+        float o2 = rm_prim_typed<ROT, SCL>(U.prims4[2], 2, p);
+        float o3 = rm_prim_typed<ROT, SCL>(U.prims4[3], 3, p);
+        return rm_smin_w(rm_smin_w(o0, o1), rm_smin_w(o2, o3));
+    }
+    RM_DI V4 full(V3 p) const {
+        V4 o[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const RmPrimDev &P = U.prims4[i];
+            o[i].w = rm_prim_typed<ROT, SCL>(P, i, p);
+            o[i].x = P.cr; o[i].y = P.cg; o[i].z = P.cb;
+        }
+        return rm_smin4(rm_smin4(o[0], o[1]), rm_smin4(o[2], o[3]));
+    }
+};
+
+// N-primitive scene from a table in global memory.  Every lane walks the table
+// with the same index, so the loads are wave-uniform and go through the scalar
+// cache.  The balanced pairwise tree "in index order" (level by level, an odd
+// last element carried up) is evaluated in one pass with a binary-counter stack:
+// after primitive i, stack[l] holds the finished subtree of 2^l leaves iff bit l
+// of (i+1) is set; leftovers are merged low level first.
+#define RM_TREE_LEVELS 11
+template <bool ROT, int SCL>
+struct SceneN {
+    const RmPrimDev *__restrict__ T;
+    int n;
+    RM_DI SceneN(const RmPrimDev *t, int n_) : T(t), n(n_) {}
+    RM_DI float w(V3 p) const {
+        float st[RM_TREE_LEVELS];
+#pragma unroll
+        for (int l = 0; l < RM_TREE_LEVELS; l++) st[l] = 0.0f;
+        for (int i = 0; i < n; i++) {
+            const RmPrimDev &P = T[i];
+            float v = rm_prim_typed<ROT, SCL>(P, P.type, p);
+            bool placed = false;
+#pragma unroll
+            for (int l = 0; l < RM_TREE_LEVELS; l++) {
+                if (!placed) {
+                    if (i & (1 << l)) v = rm_smin_w(st[l], v);
+                    else { st[l] = v; placed = true; }
+                }
+            }
+        }
+        float acc = 0.0f;
+        bool have = false;
+#pragma unroll
+        for (int l = 0; l < RM_TREE_LEVELS; l++) {
+            if (n & (1 << l)) { acc = have ? rm_smin_w(st[l], acc) : st[l]; have = true; }
+        }
+        return acc;
+    }
+    RM_DI V4 full(V3 p) const {
+        V4 st[RM_TREE_LEVELS];
+#pragma unroll
+        for (int l = 0; l < RM_TREE_LEVELS; l++) { st[l].x = st[l].y = st[l].z = st[l].w = 0.0f; }
+        for (int i = 0; i < n; i++) {
+            const RmPrimDev &P = T[i];
+            V4 v;
+            v.w = rm_prim_typed<ROT, SCL>(P, P.type, p);
+            v.x = P.cr; v.y = P.cg; v.z = P.cb;
+            bool placed = false;
+#pragma unroll
+            for (int l = 0; l < RM_TREE_LEVELS; l++) {
+                if (!placed) {
+                    if (i & (1 << l)) v = rm_smin4(st[l], v);
+                    else { st[l] = v; placed = true; }
+                }
+            }
+        }
+        V4 acc; acc.x = acc.y = acc.z = acc.w = 0.0f;
+        bool have = false;
+#pragma unroll
+        for (int l = 0; l < RM_TREE_LEVELS; l++) {
+            if (n & (1 << l)) { acc = have ? rm_smin4(st[l], acc) : st[l]; have = true; }
+        }
+        return acc;
+    }
+};
+
+RM_DI uint32_t rm_unorm8(float x) {
+    x = fminf(fmaxf(x, 0.0f), 1.0f);           // saturate; a NaN becomes 0
+    return (uint32_t)floorf(x * 255.0f + 0.5f);
+}
