@@ -1,0 +1,258 @@
+"""Second, independently written restatement of the reference's march in NumPy
+float32, vectorised over pixels.  It exists only to cross-check oracle/rm_oracle.c
+(N-version check: the reference ships no golden image to pin either of them).
+
+TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED BY THE REFERENCE.
+
+NumPy's float32 ufuncs are IEEE-754 binary32 with one rounding per operation and
+no fused multiply-add, i.e. the same arithmetic model as the C oracle.  Citations:
+"cginc" = Assets/Raymarching.cginc, "shader" = Assets/Raymarching.shader.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+f = np.float32
+
+
+def row(m, i):
+    """Row i of a column-major Unity Matrix4x4 (the shader's M[i])."""
+    m = np.asarray(m, dtype=f).reshape(16)
+    return m[i::4]
+
+
+def dot(ax, ay, az, bx, by, bz):
+    return ax * bx + ay * by + az * bz
+
+
+def length3(x, y, z):
+    return np.sqrt(dot(x, y, z, x, y, z))
+
+
+def length2(x, y):
+    return np.sqrt(x * x + y * y)
+
+
+def lerp(a, b, t):
+    return a + t * (b - a)
+
+
+def clamp(x, lo, hi):
+    return np.fmin(np.fmax(x, f(lo)), f(hi))
+
+
+def rotate_q(vx, vy, vz, q):
+    """cginc:62-66"""
+    ux, uy, uz, qw = -q[0], -q[1], -q[2], q[3]
+    a = f(2) * dot(ux, uy, uz, vx, vy, vz)
+    c = qw * qw - dot(ux, uy, uz, ux, uy, uz)
+    w2 = f(2) * qw
+    cx = uy * vz - uz * vy
+    cy = uz * vx - ux * vz
+    cz = ux * vy - uy * vx
+    return (ux * a + vx * c) + cx * w2, (uy * a + vy * c) + cy * w2, (uz * a + vz * c) + cz * w2
+
+
+def sphere(x, y, z, r=1.0):                       # cginc:169-171
+    return length3(x, y, z) - f(r) * f(.5)
+
+
+def box(x, y, z, b=(1.0, 1.0, 1.0)):              # cginc:173-177
+    bx, by, bz = f(b[0]) * f(.5), f(b[1]) * f(.5), f(b[2]) * f(.5)
+    dx, dy, dz = np.abs(x) - bx, np.abs(y) - by, np.abs(z) - bz
+    outside = length3(np.fmax(dx, f(0)), np.fmax(dy, f(0)), np.fmax(dz, f(0)))
+    return outside + np.fmin(np.fmax(dx, np.fmax(dy, dz)), f(0))
+
+
+def torus(x, y, z, tx=.5, ty=.25):                # cginc:179-182
+    return length2(length2(x, y) - f(tx), z) - f(ty)
+
+
+def link(x, y, z, le, r1, r2):                    # cginc:184-187
+    qy = np.fmax(np.abs(y) - f(le), f(0))
+    return length2(length2(x, qy) - f(r1), z) - f(r2)
+
+
+def cylinder(x, y, z, h=.5, r=.5):                # cginc:189-192
+    dx = np.abs(length2(x, z)) - f(h)
+    dy = np.abs(y) - f(r)
+    return np.fmin(np.fmax(dx, dy), f(0)) + length2(np.fmax(dx, f(0)), np.fmax(dy, f(0)))
+
+
+def smin_w(a, b, k=.5):                           # cginc:110-113, distance lane
+    k = f(k)
+    h = clamp(f(.5) + f(.5) * (b - a) / k, 0, 1)
+    return lerp(b, a, h) - k * h * (f(1) - h), h
+
+
+def blend(c1, c2, h):                             # cginc:101-103
+    mx, my, mz = lerp(c1[0], c2[0], h), lerp(c1[1], c2[1], h), lerp(c1[2], c2[2], h)
+    inv = f(1) / np.sqrt(dot(mx, my, mz, mx, my, mz))
+    l = lerp(length3(*c1), length3(*c2), h)
+    return (mx * inv) * l, (my * inv) * l, (mz * inv) * l
+
+
+class Scene:
+    COLORS = ((1, .25, .25), (.25, 1, .25), (.25, .25, 1), (1, 1, .25))     # cginc:356-359
+
+    def __init__(self, props, prims=None):
+        if prims:
+            self.prims = [dict(p) for p in prims]
+        else:
+            self.prims = []
+            par = [(1.0,), (1.0, 1.0, 1.0), (5.0, 5.0, .1), (.5, .5)]
+            for i in range(4):
+                self.prims.append({"type": i, "pos": row(props["_Positions"], i)[:3],
+                                   "quat": row(props["_Rotations"], i), "scale": row(props["_Scales"], i)[:3],
+                                   "color": self.COLORS[i], "params": par[i]})
+        for p in self.prims:
+            for k in ("pos", "quat", "scale", "color", "params"):
+                p[k] = np.asarray(p[k], dtype=f)
+
+    def prim(self, p, x, y, z):
+        """cginc:336-354: rotate(p - pos, q) / scale -> primitive -> * min(scale)"""
+        lx, ly, lz = rotate_q(x - p["pos"][0], y - p["pos"][1], z - p["pos"][2], p["quat"])
+        s = p["scale"]
+        lx, ly, lz = lx / s[0], ly / s[1], lz / s[2]
+        t, a = int(p["type"]), p["params"]
+        if t == 0:
+            d = sphere(lx, ly, lz, a[0])
+        elif t == 1:
+            d = box(lx, ly, lz, a[:3])
+        elif t == 2:
+            d = link(lx, ly, lz, a[0], a[1], a[2])
+        elif t == 3:
+            d = cylinder(lx, ly, lz, a[0], a[1])
+        else:
+            d = torus(lx, ly, lz, a[0], a[1])
+        return d * np.fmin(s[0], np.fmin(s[1], s[2]))
+
+    def eval(self, x, y, z, want_rgb=False):
+        """cginc:334-364: balanced pairwise smin level by level in index order."""
+        items = []
+        for p in self.prims:
+            d = self.prim(p, x, y, z)
+            if want_rgb:
+                c = tuple(np.full_like(d, p["color"][j]) for j in range(3))
+            else:
+                c = None
+            items.append((c, d))
+        while len(items) > 1:
+            nxt = []
+            for i in range(0, len(items) - 1, 2):
+                (ca, a), (cb, b) = items[i], items[i + 1]
+                w, h = smin_w(a, b)
+                c = blend(cb, ca, h) if want_rgb else None
+                nxt.append((c, w))
+            if len(items) & 1:
+                nxt.append(items[-1])
+            items = nxt
+        return items[0]
+
+
+def march(scene, ox, oy, oz, dx, dy, dz, depth, steps, sf, shadow=False):
+    """cginc:367-392 (raymarch) and the loop of shader:102-123 (getshadow, k=16)
+    over arrays of rays; returns hit, evals, length, res."""
+    n = ox.shape[0]
+    dm = np.zeros(n, dtype=f)
+    res = np.ones(n, dtype=f)
+    hit = np.zeros(n, dtype=bool)
+    evals = np.zeros(n, dtype=np.int32)
+    active = np.arange(n)
+    i = 0
+    with np.errstate(all="ignore"):
+        while active.size and f(i) < steps:
+            a = active
+            t = dm[a]
+            _, dts = scene.eval(ox[a] + dx[a] * t, oy[a] + dy[a] * t, oz[a] + dz[a] * t)
+            evals[a] += 1
+            if shadow:
+                res[a] = np.fmin(res[a], f(16) * dts / t)
+            t = t + np.abs(dts) * sf
+            dm[a] = t
+            contact = t * f(.0025)
+            h = np.abs(dts) < contact
+            hit[a[h]] = True
+            far = t > depth[a]
+            active = a[~h & ~far]
+            i += 1
+    return hit, evals, dm, res
+
+
+def unorm8(x):
+    with np.errstate(invalid="ignore"):
+        x = np.fmin(np.fmax(x, f(0)), f(1))
+    return np.floor(x * f(255) + f(.5)).astype(np.uint8)
+
+
+def pixel_rays(props, w, h):
+    """vert (cginc:26-33) + rasteriser interpolation to pixel centres, uv origin bottom-left."""
+    fc, c2w = props["_FrustrumCorners"], props["_CameraInvViewMatrix"]
+    corners = []
+    for i in range(4):
+        v = row(fc, i)
+        corners.append([dot(row(c2w, j)[0], row(c2w, j)[1], row(c2w, j)[2], v[0], v[1], v[2]) for j in range(3)])
+    tl, tr, br, bl = corners
+    xs = (np.arange(w, dtype=f) + f(.5)) / f(w)
+    ys = (np.arange(h, dtype=f) + f(.5)) / f(h)
+    uu, vv = np.meshgrid(xs, ys)
+    uu, vv = uu.reshape(-1), vv.reshape(-1)
+    rd = [lerp(lerp(bl[j], br[j], uu), lerp(tl[j], tr[j], uu), vv) for j in range(3)]
+    return rd
+
+
+def render(props, w, h, prims=None, src=None, scene_depth=None):
+    """shader:149-216 (frag) for every pixel.  Returns rgba u8 [h,w,4], depth, hit, stats."""
+    scene = Scene(props, prims)
+    n = w * h
+    rdx, rdy, rdz = pixel_rays(props, w, h)
+    cam = np.asarray(props["_WorldSpaceCameraPos"], dtype=f)
+    L = np.asarray(props["_WorldSpaceLightPos0"], dtype=f)
+    ox, oy, oz = (np.full(n, cam[j], dtype=f) for j in range(3))
+    steps = np.fmin(f(2000), f(props["_MaxSteps"]))
+    sf = f(props["_StepFactor"])
+    far = f(np.asarray(props["_ProjectionParams"], dtype=f)[2])
+    depth = np.full(n, far, dtype=f) if scene_depth is None else np.asarray(scene_depth, dtype=f).reshape(-1)
+    depth = np.fmin(depth, f(props["_MaxDist"]))
+    hit, ev_p, length, _ = march(scene, ox, oy, oz, rdx, rdy, rdz, depth, steps, sf)
+
+    if src is None:
+        bg = np.asarray(props["_BackgroundColor"], dtype=f)
+        col = [np.full(n, bg[j], dtype=f) for j in range(3)]
+    else:
+        s = np.asarray(src, dtype=np.uint8).reshape(n, 4)
+        col = [s[:, j].astype(f) / f(255) for j in range(3)]
+
+    idx = np.nonzero(hit)[0]
+    ev_s = np.zeros(n, dtype=np.int32)
+    if idx.size:
+        t = length[idx]
+        hx, hy, hz = ox[idx] + rdx[idx] * t, oy[idx] + rdy[idx] * t, oz[idx] + rdz[idx] * t     # shader:174
+        e = np.fmax(f(0), f(props["_NormalSampleScale"]))                                       # shader:51
+        z0 = np.zeros_like(hx)
+        nx = scene.eval(hx + e, hy + z0, hz + z0)[1] - scene.eval(hx - e, hy - z0, hz - z0)[1]
+        ny = scene.eval(hx + z0, hy + e, hz + z0)[1] - scene.eval(hx - z0, hy - e, hz - z0)[1]
+        nz = scene.eval(hx + z0, hy + z0, hz + e)[1] - scene.eval(hx - z0, hy - z0, hz - e)[1]
+        inv = f(1) / np.sqrt(dot(nx, ny, nz, nx, ny, nz))
+        ux, uy, uz = nx * inv, ny * inv, nz * inv
+        srgb, _ = scene.eval(hx, hy, hz, want_rgb=True)                                         # shader:193
+        contact = t * f(.0025)                       # value raymarch() left in _ContactThreshold (cginc:376)
+        sx, sy, sz = hx + (ux * contact) * f(2), hy + (uy * contact) * f(2), hz + (uz * contact) * f(2)
+        sd = np.full(idx.size, np.fmin(f(2000), f(props["_MaxDist"])), dtype=f)
+        lx, ly, lz = (np.full(idx.size, L[j], dtype=f) for j in range(3))
+        _, evs, _, res = march(scene, sx, sy, sz, lx, ly, lz, sd, steps, sf, shadow=True)
+        ev_s[idx] = evs
+        with np.errstate(all="ignore"):
+            shadow = (res - f(0)) / (f(1) - f(0)) * (f(1) - f(.25)) + f(.25)                    # cginc:80-82
+            ndl = dot(ux, uy, uz, L[0], L[1], L[2]) * f(.5) + f(.5)
+            nss = f(props["_NormalSampleScale"])
+            ao = clamp(length3(nx / nss, ny / nss, nz / nss), 0, 1)                             # shader:125-127
+            for j in range(3):
+                col[j][idx] = ((srgb[j] * ndl) * shadow) * ao                                   # shader:199
+    rgba = np.empty((n, 4), dtype=np.uint8)
+    for j in range(3):
+        rgba[:, j] = unorm8(col[j])
+    rgba[:, 3] = 255
+    stats = {"n_pixels": n, "n_hit": int(hit.sum()), "sum_steps_p": int(ev_p.sum()), "sum_steps_s": int(ev_s.sum())}
+    return {"rgba": rgba.reshape(h, w, 4), "depth": length.reshape(h, w), "hit": hit.astype(np.uint8).reshape(h, w),
+            "stats": stats}

@@ -1,0 +1,156 @@
+"""Named parity cases: each builds the material bindings (through the package's own
+host-side scripts, i.e. the path a user takes) plus the inputs, so that the golden
+generator, the CPU tests and the GPU tests all see identical uniforms."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from raymarching_amd import Material, Raymarching, ShadowMap, ShadowMapDirectional, scenes
+from raymarching_amd.unity import F, Transform, quat_angle_axis, quat_mul, vec3
+
+
+def _base(mat: Material, w: int, h: int, camera=None, transforms=None) -> Raymarching:
+    rm = Raymarching(camera or scenes.default_camera(w, h), mat, transforms or scenes.default_transforms())
+    rm.bind()
+    mat.SetVector("_WorldSpaceLightPos0", scenes.WORLD_SPACE_LIGHT_POS0)
+    return rm
+
+
+def transformed_transforms(pow2_scales: bool = False):
+    """the four slots with rotations and non-unit scales (general rotate()/divide path)"""
+    ts = scenes.default_transforms()
+    rots = [quat_angle_axis(33.0, (1, 2, 3)), quat_angle_axis(-71.0, (0, 1, 1)),
+            quat_mul(quat_angle_axis(20.0, (0, 0, 1)), quat_angle_axis(12.0, (1, 0, 0))), quat_angle_axis(110.0, (1, 0, 0))]
+    scl = [(1.3, 0.8, 1.1), (0.7, 1.9, 1.2), (0.9, 1.1, 1.05), (1.6, 0.6, 1.0)]
+    if pow2_scales:
+        scl = [(2.0, 1.0, 0.5), (0.5, 2.0, 1.0), (1.0, 1.0, 1.0), (2.0, 0.5, 1.0)]
+    for t, q, s in zip(ts, rots, scl):
+        t.rotation = q.astype(F)
+        t.lossyScale = np.asarray(s, dtype=F)
+    return ts
+
+
+def synthetic_src(w: int, h: int) -> np.ndarray:
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.empty((h, w, 4), dtype=np.uint8)
+    img[..., 0] = (x * 7 + y * 3) & 255
+    img[..., 1] = (x ^ y) & 255
+    img[..., 2] = (x * y) & 255
+    img[..., 3] = (x + y) & 255
+    return img
+
+
+def synthetic_depth(w: int, h: int) -> np.ndarray:
+    """a mesh-depth texture: a wall at eye depth 11.3 over the left third, far elsewhere"""
+    d = np.full((h, w), 1000.0, dtype=np.float32)
+    d[:, : w // 3] = 11.3
+    d[h // 2:, w // 3: w // 2] = 10.9
+    return d
+
+
+class Case:
+    def __init__(self, name, w, h, kind="frag", setup=None, prims=None, src=False, sdepth=False, heavy=False):
+        self.name, self.w, self.h, self.kind = name, w, h, kind
+        self._setup, self.prims, self.use_src, self.use_sdepth, self.heavy = setup, prims, src, sdepth, heavy
+        self.corners = None
+        self.forward = None
+
+    def bind(self, mat: Material):
+        """applies the case to a material; returns (src, scene_depth)"""
+        if self._setup:
+            self._setup(self, mat)
+        else:
+            _base(mat, self.w, self.h)
+        if self.prims is not None:
+            mat.SetPrimitives(self.prims)
+        src = synthetic_src(self.w, self.h) if self.use_src else None
+        sd = synthetic_depth(self.w, self.h) if self.use_sdepth else None
+        return src, sd
+
+
+def _orbit(k):
+    def f(case, mat):
+        _base(mat, case.w, case.h, camera=scenes.orbit_camera(k, 64, case.w, case.h))
+    return f
+
+
+def _transformed(pow2):
+    def f(case, mat):
+        _base(mat, case.w, case.h, transforms=transformed_transforms(pow2))
+    return f
+
+
+def _stress(case, mat):
+    _base(mat, case.w, case.h, camera=scenes.stress_camera(case.w, case.h))
+    for k, v in scenes.STRESS_FLOATS.items():
+        mat.SetFloat(k, v)
+
+
+def _fractional_steps(case, mat):
+    _base(mat, case.w, case.h)
+    mat.SetFloat("_MaxSteps", 37.5)          # slider values may be fractional: iterate while (float)i < steps
+    mat.SetFloat("_MaxDist", 30.0)
+    mat.SetFloat("_StepFactor", 0.35)
+    mat.SetFloat("_NormalSampleScale", 0.001)
+
+
+def _shadow_persp(case, mat):
+    _base(mat, case.w, case.h)
+    sm = ShadowMap(scenes.shadow_camera(case.w, case.h), mat)
+    m = sm.shadowMapMaterial
+    m.SetMatrix("_FrustrumCorners", sm.GetFrustumCorners())
+    m.SetMatrix("_CameraInvViewMatrix", sm.cam.cameraToWorldMatrix)
+    m.SetVector("_WorldSpaceCameraPos", sm.cam.transform.position)
+
+
+def _shadow_dir(case, mat):
+    _base(mat, case.w, case.h)
+    # the ShadowMap object's transform reused as the rectangle, as the survey's config 3 does:
+    # a 14 x 8 rectangle above and behind the objects, looking back at them
+    t = Transform(position=vec3(-3, 3, 9), rotation=scenes.shadow_camera().transform.rotation, lossyScale=vec3(14, 8, 1))
+    smd = ShadowMapDirectional(t, mat)
+    smd.Update()
+    case.corners = np.stack(smd.corners).astype(F).reshape(12)
+    case.forward = t.forward.astype(F)
+
+
+CASES = [
+    Case("default_640x360", 640, 360),
+    Case("default_1920x1080", 1920, 1080, heavy=True),
+    Case("default_3840x2160", 3840, 2160, heavy=True),
+    Case("default_src_depth_333x187", 333, 187, src=True, sdepth=True),      # ragged size, _MainTex + depth texture
+    Case("orbit_k5_480x270", 480, 270, setup=_orbit(5)),
+    Case("orbit_k23_480x270", 480, 270, setup=_orbit(23)),
+    Case("orbit_k40_480x270", 480, 270, setup=_orbit(40)),
+    Case("transformed_400x225", 400, 225, setup=_transformed(False)),
+    Case("transformed_pow2_400x225", 400, 225, setup=_transformed(True)),
+    Case("fractional_steps_320x180", 320, 180, setup=_fractional_steps),
+    Case("tiny_1x1", 1, 1),
+    Case("tiny_17x3", 17, 3),
+    Case("stress256_320x180", 320, 180, setup=_stress, prims=scenes.stress_primitives(256)),
+    Case("stress13_200x112", 200, 112, setup=_stress, prims=scenes.stress_primitives(13, seed=0x5EED000D)),
+    Case("prims4_as_table_320x180", 320, 180, prims=[
+        {"type": 0, "pos": (-0.584, 0.049, 0.602), "quat": (0, 0, 0, 1), "scale": (1, 1, 1), "color": (1, .25, .25), "params": (1,)},
+        {"type": 1, "pos": (-0.74, 0.929, 0.0), "quat": (0, 0, 0, 1), "scale": (1, 1, 1), "color": (.25, 1, .25), "params": (1, 1, 1)},
+        {"type": 2, "pos": (-7.87, 0.0, 1.522), "quat": (0, 0, 0, 1), "scale": (1, 1, 1), "color": (.25, .25, 1), "params": (5, 5, .1)},
+        {"type": 3, "pos": (-3.074, -0.087, 0.08), "quat": (0, 0, 0, 1), "scale": (1, 1, 1), "color": (1, 1, .25), "params": (.5, .5)},
+    ]),
+    Case("shadow_persp_100x100", 100, 100, kind="shadow_persp", setup=_shadow_persp),
+    Case("shadow_dir_256x144", 256, 144, kind="shadow_dir", setup=_shadow_dir),
+]
+
+BY_NAME = {c.name: c for c in CASES}
+
+
+def oracle_run(case: Case, O, threads: int = 0) -> dict:
+    """binds the case on a fresh material and renders it with the CPU oracle"""
+    with Material() as mat:
+        src, sd = case.bind(mat)
+        uni = O.Uniforms(O.props_from_material(mat), prims=case.prims)
+        if case.kind == "frag":
+            return O.render(uni, case.w, case.h, src=src, scene_depth=sd, threads=threads, want_steps=True)
+        if case.kind == "shadow_persp":
+            return O.shadowmap_perspective(uni, case.w, case.h, threads=threads)
+        return O.shadowmap_directional(uni, case.corners, case.forward, case.w, case.h, threads=threads)

@@ -1,0 +1,203 @@
+"""Parity of the HIP path, called through the C ABI, against the CPU oracle on
+identical uniforms, against the committed golden hashes at full sizes, and through
+size-independent properties (band/pose decomposition, determinism, counters)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from helpers import assert_frame_equal, sha
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "golden.json")) as f:
+    GOLD = json.load(f)["cases"]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from raymarching_amd import native
+    assert os.path.exists(native.LIB_PATH), "librmhip.so must be built before the GPU tests"
+    return torch
+
+
+def gpu_run(case, torch, host_path=False):
+    """binds the case and renders it through the C ABI (device pointers unless host_path)"""
+    from raymarching_amd import Graphics, Material, RenderTexture
+    from raymarching_amd.material import _fp, _ptr, current_stream_handle
+    with Material() as mat:
+        src, sd = case.bind(mat)
+        dev = None if host_path else "cuda:0"
+        rt = RenderTexture(case.w, case.h, device=dev)
+        lib, h = mat._lib, mat.handle
+        if case.kind == "frag":
+            if host_path:
+                s = RenderTexture(case.w, case.h) if src is not None else None
+                if s is not None:
+                    s.color[...] = src
+                Graphics.Blit(s, rt, mat, scene_depth=sd)
+            else:
+                s = None
+                if src is not None:
+                    s = RenderTexture(case.w, case.h, device=dev)
+                    s.color.copy_(torch.from_numpy(src))
+                d = torch.from_numpy(sd).to(dev) if sd is not None else None
+                Graphics.Blit(s, rt, mat, scene_depth=d)
+        elif case.kind == "shadow_persp":
+            if host_path:
+                mat._ck(lib.rm_shadowmap_render(h, _ptr(rt.depth), case.w, case.h))
+            else:
+                mat._ck(lib.rm_shadowmap_render_device(h, _ptr(rt.depth), _ptr(rt.hit), case.w, case.h,
+                                                       current_stream_handle(dev)))
+        else:
+            c, f = np.ascontiguousarray(case.corners), np.ascontiguousarray(case.forward)
+            if host_path:
+                mat._ck(lib.rm_shadowmap_directional(h, _fp(c), _fp(f), _ptr(rt.depth), case.w, case.h))
+            else:
+                mat._ck(lib.rm_shadowmap_directional_device(h, _fp(c), _fp(f), _ptr(rt.depth), _ptr(rt.hit), case.w,
+                                                            case.h, current_stream_handle(dev)))
+        st = mat.stats()
+        if host_path:
+            return {"rgba": rt.color, "depth": rt.depth, "hit": rt.hit, "stats": st}
+        torch.cuda.synchronize()
+        return {"rgba": rt.color.cpu().numpy(), "depth": rt.depth.cpu().numpy(), "hit": rt.hit.cpu().numpy(), "stats": st}
+
+
+@pytest.mark.parametrize("name", [c.name for c in cases.CASES if not c.heavy])
+def test_gpu_equals_oracle(oracle, torch_cuda, name):
+    case = cases.BY_NAME[name]
+    ref = cases.oracle_run(case, oracle)
+    got = gpu_run(case, torch_cuda)
+    if case.kind == "frag":
+        assert_frame_equal(got, ref, name)
+        assert got["stats"]["sum_steps_s"] == ref["stats"]["sum_steps_s"]
+    else:
+        assert np.array_equal(got["hit"], ref["hit"])
+        assert np.array_equal(got["depth"].view(np.uint32), ref["depth"].view(np.uint32))
+    assert got["stats"]["n_hit"] == int(ref["hit"].sum()) == int(got["hit"].sum())
+    assert got["stats"]["sum_steps_p"] == ref["stats"]["sum_steps_p"]
+    assert got["stats"]["n_pixels"] == case.w * case.h
+
+
+@pytest.mark.parametrize("name", ["default_1920x1080", "default_3840x2160"])
+def test_gpu_full_size_matches_golden_hashes(torch_cuda, name):
+    """BASELINE sizes (1080p, 4K) against the oracle's committed hashes"""
+    case, g = cases.BY_NAME[name], GOLD[name]
+    got = gpu_run(case, torch_cuda)
+    assert sha(got["hit"]) == g["sha_hit"]
+    assert sha(got["depth"]) == g["sha_depth"]
+    assert sha(got["rgba"]) == g["sha_rgba"]
+    assert got["stats"]["n_hit"] == g["n_hit"]
+    assert got["stats"]["sum_steps_p"] == g["sum_steps_p"] and got["stats"]["sum_steps_s"] == g["sum_steps_s"]
+
+
+@pytest.mark.parametrize("name", ["default_src_depth_333x187", "shadow_persp_100x100", "shadow_dir_256x144", "tiny_17x3"])
+def test_host_pointer_path_equals_device_path(torch_cuda, name):
+    case = cases.BY_NAME[name]
+    a, b = gpu_run(case, torch_cuda), gpu_run(case, torch_cuda, host_path=True)
+    assert np.array_equal(a["depth"].view(np.uint32), b["depth"].view(np.uint32))
+    if case.kind == "frag":
+        assert np.array_equal(a["rgba"], b["rgba"]) and np.array_equal(a["hit"], b["hit"])
+
+
+@pytest.mark.parametrize("w,h,band,parts", [(1920, 1080, 8, 3), (3840, 2160, 8, 8), (333, 187, 5, 4), (64, 7, 8, 2)])
+def test_band_shards_reassemble_to_the_full_frame(torch_cuda, w, h, band, parts):
+    """a frame rendered as interleaved row bands (the multi-GPU decomposition) equals the one-call frame"""
+    torch = torch_cuda
+    from raymarching_amd import Material, Raymarching, RenderTexture, scenes
+    from raymarching_amd.material import _ptr, current_stream_handle
+    with Material() as mat:
+        rm = Raymarching(scenes.default_camera(w, h), mat, scenes.default_transforms())
+        mat.SetVector("_WorldSpaceLightPos0", scenes.WORLD_SPACE_LIGHT_POS0)
+        full = RenderTexture(w, h, device="cuda:0")
+        rm.OnRenderImage(None, full)
+        full_stats = mat.stats()
+        out_c = torch.zeros_like(full.color)
+        out_d = torch.zeros_like(full.depth)
+        out_h = torch.zeros_like(full.hit)
+        tot = {"n_hit": 0, "sum_steps_p": 0, "sum_steps_s": 0, "n_pixels": 0}
+        ys = torch.arange(h, device="cuda:0")
+        for p in range(parts):
+            rows = mat._lib.rm_band_rows(h, band, p, parts)
+            if rows == 0:
+                continue
+            c = torch.zeros((rows, w, 4), dtype=torch.uint8, device="cuda:0")
+            d = torch.zeros((rows, w), dtype=torch.float32, device="cuda:0")
+            m = torch.zeros((rows, w), dtype=torch.uint8, device="cuda:0")
+            mat._ck(mat._lib.rm_blit_bands_device(mat.handle, None, None, _ptr(c), _ptr(d), _ptr(m), w, h, band, p,
+                                                  parts, current_stream_handle("cuda:0")))
+            st = mat.stats()
+            for k in tot:
+                tot[k] += st[k]
+            sel = ((ys // band) % parts) == p
+            out_c[sel], out_d[sel], out_h[sel] = c, d, m
+        torch.cuda.synchronize()
+        assert torch.equal(out_c, full.color) and torch.equal(out_h, full.hit)
+        assert torch.equal(out_d.view(torch.int32), full.depth.view(torch.int32))
+        assert tot == {k: full_stats[k] for k in tot}
+
+
+def test_pose_batch_equals_single_blits(oracle, torch_cuda):
+    """rm_blit_poses_device over 5 orbit poses == 5 x (SetMatrix x2 + Blit), and pose 3 == the oracle"""
+    torch = torch_cuda
+    from raymarching_amd import Material, Raymarching, RenderTexture, scenes
+    from raymarching_amd.material import _fp, _ptr, current_stream_handle
+    w, h, ks = 480, 270, [0, 9, 23, 40, 63]
+    with Material() as mat:
+        singles = []
+        fcs, c2ws, pos = [], [], []
+        for k in ks:
+            rm = Raymarching(scenes.orbit_camera(k, 64, w, h), mat, scenes.default_transforms())
+            mat.SetVector("_WorldSpaceLightPos0", scenes.WORLD_SPACE_LIGHT_POS0)
+            rt = RenderTexture(w, h, device="cuda:0")
+            rm.OnRenderImage(None, rt)
+            singles.append(rt)
+            fcs.append(rm.GetFrustumCorners().m)
+            c2ws.append(rm.cam.cameraToWorldMatrix.m)
+            pos.append(rm.cam.transform.position)
+        n = len(ks)
+        fcs = np.ascontiguousarray(np.stack(fcs), dtype=np.float32)
+        c2ws = np.ascontiguousarray(np.stack(c2ws), dtype=np.float32)
+        pos = np.ascontiguousarray(np.stack(pos), dtype=np.float32)
+        c = torch.zeros((n, h, w, 4), dtype=torch.uint8, device="cuda:0")
+        d = torch.zeros((n, h, w), dtype=torch.float32, device="cuda:0")
+        m = torch.zeros((n, h, w), dtype=torch.uint8, device="cuda:0")
+        mat._ck(mat._lib.rm_blit_poses_device(mat.handle, n, _fp(fcs), _fp(c2ws), _fp(pos), _ptr(c), _ptr(d), _ptr(m), w, h,
+                                              current_stream_handle("cuda:0")))
+        st = mat.stats()
+        torch.cuda.synchronize()
+        assert st["n_pixels"] == n * w * h and st["n_hit"] == int(m.sum())
+        for i in range(n):
+            assert torch.equal(c[i], singles[i].color) and torch.equal(m[i], singles[i].hit)
+            assert torch.equal(d[i].view(torch.int32), singles[i].depth.view(torch.int32))
+    ref = cases.oracle_run(cases.BY_NAME["orbit_k23_480x270"], oracle)
+    assert np.array_equal(c[2].cpu().numpy(), ref["rgba"])
+
+
+def test_repeat_runs_are_identical_and_counters_reset(torch_cuda):
+    case = cases.BY_NAME["default_640x360"]
+    a, b = gpu_run(case, torch_cuda), gpu_run(case, torch_cuda)
+    assert sha(a["rgba"]) == sha(b["rgba"]) and sha(a["depth"]) == sha(b["depth"])
+    assert a["stats"] == b["stats"]
+    assert a["stats"]["n_hit"] == int(a["hit"].sum())
+
+
+def test_changing_a_uniform_changes_the_frame(torch_cuda):
+    """guards against a cached/stale parameter block"""
+    torch = torch_cuda
+    from raymarching_amd import Material, Raymarching, RenderTexture, scenes
+    with Material() as mat:
+        rm = Raymarching(scenes.default_camera(320, 180), mat, scenes.default_transforms())
+        mat.SetVector("_WorldSpaceLightPos0", scenes.WORLD_SPACE_LIGHT_POS0)
+        a, b = RenderTexture(320, 180, device="cuda:0"), RenderTexture(320, 180, device="cuda:0")
+        rm.OnRenderImage(None, a)
+        rm.transforms[0].position = np.array([-0.584, 1.5, 0.602], dtype=np.float32)
+        rm.OnRenderImage(None, b)
+        torch.cuda.synchronize()
+        assert not torch.equal(a.color, b.color)

@@ -1,0 +1,160 @@
+"""Known-answer tests that follow from the closed forms of the reference's SDFs
+(Assets/Raymarching.cginc).  The reference ships no test vectors, so these pin the
+oracle to the formulas themselves."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle.rm_oracle import RmoUniforms, Uniforms, f32, fp
+
+F = np.float32
+
+
+def p3(x, y, z):
+    return fp(f32([x, y, z]))
+
+
+def test_sphere(oracle):                       # cginc:169-171
+    l = oracle.lib()
+    assert l.rmo_sphere(p3(1, 0, 0), 1.0) == 0.5
+    assert l.rmo_sphere(p3(0, 0, 0), 1.0) == -0.5
+    assert l.rmo_sphere(p3(0, 3, 4), 2.0) == 4.0
+
+
+def test_box(oracle):                          # cginc:173-177
+    l = oracle.lib()
+    b = fp(f32([1, 1, 1]))
+    assert l.rmo_box(p3(1, 0, 0), b) == 0.5
+    assert l.rmo_box(p3(0, 0, 0), b) == -0.5
+    assert l.rmo_box(p3(0.5, 0.5, 0.5), b) == 0.0
+    assert l.rmo_box(p3(3.5, 4.5, 0), b) == 5.0            # corner distance 3-4-5
+
+
+def test_cylinder(oracle):                     # cginc:189-192: h is the radius, r the half height
+    l = oracle.lib()
+    assert l.rmo_cylinder(p3(1, 0, 0), .5, .5) == 0.5
+    assert l.rmo_cylinder(p3(0, 1, 0), .5, .5) == 0.5
+    assert l.rmo_cylinder(p3(0, 0, 0), .5, .5) == -0.5
+    assert l.rmo_cylinder(p3(0, 0, 2), .5, .25) == 1.5
+
+
+def test_link(oracle):                         # cginc:184-187 with (5,5,.1)
+    l = oracle.lib()
+    assert l.rmo_link(p3(0, 0, 0), 5, 5, .1) == pytest.approx(4.9, abs=1e-6)
+    assert l.rmo_link(p3(5, 0, 0), 5, 5, .1) == pytest.approx(-0.1, abs=1e-7)
+    assert l.rmo_link(p3(0, 10, 0), 5, 5, .1) == pytest.approx(-0.1, abs=1e-7)   # top of the rounded end
+    assert l.rmo_link(p3(5, 3, 2), 5, 5, .1) == pytest.approx(1.9, abs=1e-6)     # straight section
+
+
+def test_torus(oracle):                        # cginc:179-182
+    l = oracle.lib()
+    assert l.rmo_torus(p3(.5, 0, 0), .5, .25) == -0.25
+    assert l.rmo_torus(p3(0, 0, 0), .5, .25) == 0.25
+
+
+def test_smin(oracle):                         # cginc:110-113
+    l = oracle.lib()
+    out = f32([0, 0, 0, 0])
+
+    def w(a, b):
+        l.rmo_smin4(fp(f32([1, 0, 0, a])), fp(f32([0, 1, 0, b])), 0.5, fp(out))
+        return float(out[3])
+    assert w(0, 1) == 0.0
+    assert w(1, 0) == 0.0
+    assert w(0, 0) == -0.125
+    assert w(0.25, 0.25) == 0.125
+    # colour: far apart -> the nearer operand's colour, renormalised to its own length
+    l.rmo_smin4(fp(f32([1, .25, .25, 0])), fp(f32([.25, 1, .25, 5])), 0.5, fp(out))
+    np.testing.assert_allclose(out[:3], [1, .25, .25], rtol=3e-7)
+    # equal distances: h = .5, colour = normalize(mid) * mean length
+    l.rmo_smin4(fp(f32([1, 0, 0, 1])), fp(f32([0, 1, 0, 1])), 0.5, fp(out))
+    np.testing.assert_allclose(out[:3], [math.sqrt(.5), math.sqrt(.5), 0], rtol=3e-7)
+
+
+def test_rotate_and_remap(oracle):             # cginc:62-66, 80-82
+    l = oracle.lib()
+    out = f32([0, 0, 0])
+    l.rmo_rotate_q(p3(1, 2, 3), fp(f32([0, 0, 0, 1])), fp(out))
+    assert out.tolist() == [1, 2, 3]
+    s = math.sqrt(.5)
+    l.rmo_rotate_q(p3(1, 0, 0), fp(f32([0, 0, s, s])), fp(out))          # +90 deg about z, applied as the conjugate
+    np.testing.assert_allclose(out, [0, -1, 0], atol=1e-7)
+    assert l.rmo_remap(0, 0, 1, .25, 1) == 0.25
+    assert l.rmo_remap(1, 0, 1, .25, 1) == 1.0
+    assert l.rmo_remap(.5, 0, 1, .25, 1) == 0.625
+
+
+def test_vert_corner_index(oracle):            # cginc:30 with Raymarching.cs:50-53
+    l = oracle.lib()
+    assert l.rmo_vert_corner_index(0, 1) == 0      # top left
+    assert l.rmo_vert_corner_index(1, 1) == 1      # top right
+    assert l.rmo_vert_corner_index(1, 0) == 2      # bottom right
+    assert l.rmo_vert_corner_index(0, 0) == 3      # bottom left
+
+
+def test_pixel_rays_and_centre_miss(oracle, default_setup):
+    _, _, props = default_setup(640, 360)
+    uni = Uniforms(props)
+    l = oracle.lib()
+    rd = f32([0, 0, 0])
+    # un-normalised rays with world z = +1 for the identity camera: dm is linear eye depth
+    for (x, y) in [(0, 0), (639, 359), (320, 180), (17, 300)]:
+        l.rmo_pixel_ray(uni.ref, x, y, 640, 360, fp(rd))
+        assert rd[2] == 1.0
+    t = math.tan(math.radians(40.0))
+    l.rmo_pixel_ray(uni.ref, 0, 0, 640, 360, fp(rd))
+    np.testing.assert_allclose(rd[:2], [-t * 16 / 9 * (1 - 1 / 640), -t * (1 - 1 / 360)], rtol=2e-6)
+    # the centre-of-screen ray points down +z and misses (the geometry is left of centre)
+    ro = f32(props["_WorldSpaceCameraPos"][:3])
+    length = f32([0])
+    import ctypes as C
+    ev = C.c_int()
+    hit = l.rmo_raymarch(uni.ref, fp(ro), fp(f32([0, 0, 1])), 1000.0, fp(length), C.byref(ev))
+    assert hit == 0 and length[0] > 50.0
+    # a ray aimed at the sphere hits it at its front surface: centre distance minus radius
+    c = f32([-0.584, 0.049, 0.602])
+    d = (c - ro) / (c - ro)[2]
+    hit = l.rmo_raymarch(uni.ref, fp(ro), fp(f32(d)), 1000.0, fp(length), C.byref(ev))
+    assert hit == 1
+    dist = float(length[0]) * float(np.linalg.norm(d))
+    assert dist == pytest.approx(float(np.linalg.norm(c - ro)) - 0.5, rel=5e-3)
+
+
+def test_scene_is_smin_tree(oracle, default_setup):
+    """scene(p).w == smin(smin(o0,o1), smin(o2,o3)) built from the primitive probes (cginc:363)."""
+    _, _, props = default_setup(64, 36)
+    uni = Uniforms(props)
+    l = oracle.lib()
+    rng = np.random.default_rng(1)
+    pos = np.asarray(props["_Positions"], dtype=F).reshape(4, 4).T
+    out, s01, s23, s = f32([0] * 4), f32([0] * 4), f32([0] * 4), f32([0] * 4)
+    cols = [(1, .25, .25), (.25, 1, .25), (.25, .25, 1), (1, 1, .25)]
+    for _ in range(200):
+        p = f32(rng.uniform([-13, -6, -2], [1, 6, 3]))
+        q = [f32(p - pos[i, :3]) for i in range(4)]
+        o = [l.rmo_sphere(fp(q[0]), 1.0), l.rmo_box(fp(q[1]), fp(f32([1, 1, 1]))),
+             l.rmo_link(fp(q[2]), 5, 5, .1), l.rmo_cylinder(fp(q[3]), .5, .5)]
+        v = [f32(list(cols[i]) + [o[i]]) for i in range(4)]
+        l.rmo_smin4(fp(v[0]), fp(v[1]), .5, fp(s01))
+        l.rmo_smin4(fp(v[2]), fp(v[3]), .5, fp(s23))
+        l.rmo_smin4(fp(s01), fp(s23), .5, fp(s))
+        l.rmo_scene(uni.ref, fp(p), fp(out))
+        assert out.tobytes() == s.tobytes()
+
+
+def test_unorm8_roundtrip_of_source_bytes(oracle, default_setup):
+    """tex = byte/255 shown on a miss pixel quantises back to the same byte."""
+    mat, _, props = default_setup(256, 1)
+    # camera looking away from everything: all pixels miss
+    props = dict(props)
+    props["_WorldSpaceCameraPos"] = f32([0, 500, 0, 0])
+    src = np.zeros((1, 256, 4), dtype=np.uint8)
+    src[0, :, 0] = np.arange(256)
+    src[0, :, 1] = np.arange(256)[::-1]
+    src[0, :, 2] = 7
+    src[0, :, 3] = 3
+    out = oracle.render(Uniforms(props), 256, 1, src=src)
+    assert out["stats"]["n_hit"] == 0
+    assert np.array_equal(out["rgba"][..., :3], src[..., :3])
+    assert (out["rgba"][..., 3] == 255).all()
