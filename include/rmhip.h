@@ -163,6 +163,10 @@ int rm_shadowmap_directional_device(rm_ctx *ctx, const float corners[12], const 
  * step-count heat map, Assets/Raymarching.shader:203).  rm_get_stats waits for
  * the stream of the last call and returns that call's counters. */
 int rm_get_stats(rm_ctx *ctx, rm_stats *out);
+/* Developer aid, no counterpart in the reference: copies the raw per-workgroup counter
+ * slots of the last call (words_per_slot 32-bit words each: hit pixels, primary
+ * evaluations, shadow evaluations, then build-specific words) to host memory. */
+int rm_debug_counter_slots(rm_ctx *ctx, uint32_t *out, int max_words, int *words_per_slot, int *n_slots);
 /* kernel variant for the next blits: 0 = auto */
 int rm_set_kernel(rm_ctx *ctx, int variant);
 

@@ -54,7 +54,9 @@ struct rm_ctx {
     int kernel = RM_KERNEL_AUTO;
 
     hipStream_t stream = nullptr;           // used by the host-pointer entry points
-    unsigned long long *d_stats = nullptr;  // 4 counters
+    unsigned long long *d_stats = nullptr;  // reduced counters of the last launch (filled by rm_get_stats)
+    uint32_t *d_partials = nullptr; size_t d_partials_cap = 0;   // per-block counter slots of the last launch
+    unsigned last_blocks = 0;
     RmPrimDev *d_prims = nullptr;  size_t d_prims_cap = 0;
     RmView *d_views = nullptr;     size_t d_views_cap = 0;
     void *d_stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // src, sdepth, rgba, depth, hit
@@ -267,7 +269,6 @@ int build_params(rm_ctx *c, RmParams *U, hipStream_t stream) {
     U->bg_rgba8 = unorm8(bg[0]) | (unorm8(bg[1]) << 8) | (unorm8(bg[2]) << 16) | 0xFF000000u;
     U->band_rows = 1; U->part = 0; U->n_parts = 1;
     U->n_poses = 1;
-    U->stats = c->d_stats;
 
     int flags = RM_SF_IDENT_ROT | RM_SF_UNIT_SCALE | RM_SF_RCP;
     if (c->prims.empty()) {
@@ -312,8 +313,18 @@ int check_size(rm_ctx *c, int w, int h) {
 }
 
 int launch(rm_ctx *c, const RmParams &U, hipStream_t stream) {
-    RM_HIP(c, hipMemsetAsync(c->d_stats, 0, 4 * sizeof(unsigned long long), stream));
-    RM_HIP(c, rm_launch_tiles(U, stream));
+    unsigned n_blocks = rm_tile_blocks(U.w, U.rows, U.n_poses);
+    if ((size_t)n_blocks * 4 * rm_slot_words() > c->d_partials_cap) {
+        // growing the slot buffer frees the old one: earlier launches must have finished with it
+        RM_HIP(c, hipStreamSynchronize(stream));
+        if (c->have_last) RM_HIP(c, hipStreamSynchronize(c->last_stream));
+        int rc = ensure_cap(c, &c->d_partials, &c->d_partials_cap, (size_t)n_blocks * 4 * rm_slot_words());
+        if (rc) return rc;
+    }
+    RmParams P = U;
+    P.partials = c->d_partials;
+    RM_HIP(c, rm_launch_tiles(P, stream));
+    c->last_blocks = n_blocks;
     c->last_stream = stream;
     c->last_pixels = (uint64_t)U.w * (uint64_t)U.rows * (uint64_t)U.n_poses;
     c->have_last = true;
@@ -347,6 +358,7 @@ void rm_destroy(rm_ctx *c) {
         if (c->d_prims) (void)hipFree(c->d_prims);
         if (c->d_views) (void)hipFree(c->d_views);
         if (c->d_stats) (void)hipFree(c->d_stats);
+        if (c->d_partials) (void)hipFree(c->d_partials);
         if (c->stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
@@ -570,13 +582,28 @@ int rm_shadowmap_directional(rm_ctx *c, const float corners[12], const float for
     return depth_pass_host(c, RM_MODE_DEPTH_ORTHO, corners, forward, depth, w, h);
 }
 
+int rm_debug_counter_slots(rm_ctx *c, uint32_t *out, int max_words, int *words_per_slot, int *n_slots) {
+    if (!c || !c->have_last) return fail(c, RM_E_ARG, "rm_debug_counter_slots: no blit has run");
+    RM_HIP(c, hipSetDevice(c->device));
+    RM_HIP(c, hipStreamSynchronize(c->last_stream));
+    size_t words = (size_t)c->last_blocks * rm_slot_words();
+    if (words_per_slot) *words_per_slot = (int)rm_slot_words();
+    if (n_slots) *n_slots = (int)c->last_blocks;
+    if (out && max_words > 0) {
+        if (words > (size_t)max_words) words = (size_t)max_words;
+        RM_HIP(c, hipMemcpy(out, c->d_partials, words * 4, hipMemcpyDeviceToHost));
+    }
+    return RM_OK;
+}
+
 int rm_get_stats(rm_ctx *c, rm_stats *out) {
     if (!c || !out) return fail(c, RM_E_ARG, "rm_get_stats: null argument");
     if (!c->have_last) return fail(c, RM_E_ARG, "rm_get_stats: no blit has run");
     RM_HIP(c, hipSetDevice(c->device));
+    RM_HIP(c, rm_reduce_stats(c->d_partials, c->last_blocks, c->d_stats, c->last_stream));
     RM_HIP(c, hipStreamSynchronize(c->last_stream));
     unsigned long long v[4];
-    RM_HIP(c, hipMemcpy(v, c->d_stats, sizeof v, hipMemcpyDeviceToHost));
+    RM_HIP(c, hipMemcpy(v, c->d_stats, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     out->n_pixels = c->last_pixels;
     out->n_hit = v[0];
     out->sum_steps_p = v[1];

@@ -75,6 +75,6 @@ struct RmParams {
     uint8_t  *dst_rgba;
     float    *dst_depth;
     uint8_t  *dst_hit;
-    unsigned long long *stats; // [0] n_hit [1] sum primary evals [2] sum shadow evals
+    uint32_t *partials;        // 3 counters per block: n_hit, primary evals, shadow evals
     RmPrimDev prims4[4];
 };

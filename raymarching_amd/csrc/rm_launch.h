@@ -8,3 +8,10 @@ enum { RM_KERNEL_AUTO = 0, RM_KERNEL_TILE = 1 };
 
 // one-thread-per-pixel tile kernel over U.w x U.rows x U.n_poses
 hipError_t rm_launch_tiles(const RmParams &U, hipStream_t stream);
+
+// 32-bit words per counter slot
+unsigned rm_slot_words();
+// number of blocks (= counter slots) rm_launch_tiles uses for a launch of this shape
+unsigned rm_tile_blocks(int w, int rows, int n_poses);
+// sums n_blocks counter slots into out[0..2] (device memory)
+hipError_t rm_reduce_stats(const unsigned *partials, unsigned n_blocks, unsigned long long *out, hipStream_t stream);

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librmhip.so")
+LIB_PATH = os.environ.get("RMHIP_LIB") or os.path.join(_HERE, "librmhip.so")   # RMHIP_LIB: developer override for A/B builds
 
 RM_OK, RM_E_ARG, RM_E_DEVICE, RM_E_NOMEM, RM_E_RANGE = 0, -1, -2, -3, -4
 RM_SPHERE, RM_BOX, RM_LINK, RM_CYLINDER, RM_TORUS = range(5)
@@ -63,6 +63,7 @@ SYMBOLS = [
     ("rm_shadowmap_directional", C.c_int, [_P, _FP, _FP, _P, C.c_int, C.c_int]),
     ("rm_shadowmap_directional_device", C.c_int, [_P, _FP, _FP, _P, _P, C.c_int, C.c_int, _P]),
     ("rm_get_stats", C.c_int, [_P, C.POINTER(RmStats)]),
+    ("rm_debug_counter_slots", C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("rm_set_kernel", C.c_int, [_P, C.c_int]),
 ]
 

@@ -1,0 +1,60 @@
+// Exhaustive check: candidate correctly-rounded sqrt sequences vs the compiler's
+// correctly rounded sqrtf over every binary32 in [2^-96, 2^96] plus 0.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+__device__ __forceinline__ float cand_a(float x) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    uint32_t sb = __float_as_uint(s);
+    uint32_t dn = __builtin_elementwise_sub_sat(sb, 1u);
+    float s_dn = __uint_as_float(dn), s_up = __uint_as_float(sb + 1u);
+    float h_dn = __builtin_fmaf(s_dn, s, -x);
+    float h_up = __builtin_fmaf(s_up, s, -x);
+    int m = (__float_as_int(h_dn) >> 31) + (__float_as_int(h_up) >> 31);
+    return __uint_as_float(dn - (uint32_t)m);
+}
+
+__global__ void check(uint32_t first, unsigned long long *bad, uint32_t *example) {
+    uint32_t bits = first + blockIdx.x * blockDim.x + threadIdx.x;
+    float x = __uint_as_float(bits);
+    float ref = (float)sqrt((double)x);
+    float ref2 = sqrtf(x);
+    if (__float_as_uint(ref) != __float_as_uint(ref2)) atomicAdd(bad + 4, 1ull);
+    float got = cand_a(x);
+    if (__float_as_uint(ref) != __float_as_uint(got)) {
+        atomicAdd(bad, 1ull);
+        example[0] = bits;
+    }
+}
+
+__global__ void raw_ulp(uint32_t first, unsigned long long *cnt) {   // how often is v_sqrt_f32 itself already correct?
+    uint32_t bits = first + blockIdx.x * blockDim.x + threadIdx.x;
+    float x = __uint_as_float(bits);
+    int d = (int)__float_as_uint(__builtin_amdgcn_sqrtf(x)) - (int)__float_as_uint((float)sqrt((double)x));
+    if (d == 0) atomicAdd(&cnt[0], 1ull); else if (d == 1 || d == -1) atomicAdd(&cnt[1], 1ull); else atomicAdd(&cnt[2], 1ull);
+}
+
+int main() {
+    unsigned long long *bad, h[5] = {0, 0, 0, 0, 0};
+    uint32_t *ex, hex = 0;
+    hipMalloc(&bad, 40); hipMalloc(&ex, 4);
+    hipMemset(bad, 0, 40); hipMemset(ex, 0, 4);
+    // exponents 127-96 .. 127+96 -> bits [ (31<<23), (224<<23) )
+    uint32_t lo = 31u << 23, hi = 224u << 23;
+    unsigned long long total = 0;
+    for (uint64_t b = lo; b < hi; b += (1u << 28)) {
+        uint32_t n = (uint32_t)((hi - b) < (1u << 28) ? (hi - b) : (1u << 28));
+        hipLaunchKernelGGL(check, dim3(n / 256), dim3(256), 0, 0, (uint32_t)b, bad, ex);
+        hipLaunchKernelGGL(raw_ulp, dim3(n / 256), dim3(256), 0, 0, (uint32_t)b, bad + 1);
+        total += n;
+    }
+    hipLaunchKernelGGL(check, dim3(1), dim3(256), 0, 0, 0u, bad, ex);      // 0 and the smallest denormals
+    hipDeviceSynchronize();
+    hipMemcpy(h, bad, 40, hipMemcpyDeviceToHost);
+    hipMemcpy(&hex, ex, 4, hipMemcpyDeviceToHost);
+    printf("checked %llu values: candidate mismatches %llu (example bits 0x%08x)\n", total, h[0], hex);
+    printf("sqrtf() vs (float)sqrt(double): %llu mismatches\n", h[4]);
+    printf("raw v_sqrt_f32: exact %llu, off by 1 ulp %llu, worse %llu\n", h[1], h[2], h[3]);
+    return h[0] != 0;
+}
