@@ -62,6 +62,14 @@ struct rm_ctx {
     void *d_stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // src, sdepth, rgba, depth, hit
     size_t d_stage_cap[5] = {0, 0, 0, 0, 0};
 
+    // persistent-kernel queue state (see RmQueue)
+    uint32_t *d_queue = nullptr; size_t d_queue_cap = 0;   // counters | heavy_count | heavy_list | flags
+    uint32_t q_tiles_cap = 0;      // flags capacity in tiles
+    uint32_t q_epoch = 0;
+    uint32_t q_last_tiles = 0, q_last_tx = 0, q_last_ty = 0; int q_last_mode = -1;
+    int n_cus = 0;
+    int occ[6][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};   // resident blocks per CU by kernel variant
+
     hipStream_t last_stream = nullptr;
     uint64_t last_pixels = 0;
     bool have_last = false;
@@ -235,6 +243,9 @@ int ensure_device(rm_ctx *c) {
     if (c->dev_ready) return RM_OK;
     RM_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     RM_HIP(c, hipMalloc((void **)&c->d_stats, 4 * sizeof(unsigned long long)));
+    hipDeviceProp_t prop;
+    RM_HIP(c, hipGetDeviceProperties(&prop, c->device));
+    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->dev_ready = true;
     return RM_OK;
 }
@@ -312,19 +323,97 @@ int check_size(rm_ctx *c, int w, int h) {
     return RM_OK;
 }
 
-int launch(rm_ctx *c, const RmParams &U, hipStream_t stream) {
-    unsigned n_blocks = rm_tile_blocks(U.w, U.rows, U.n_poses);
-    if ((size_t)n_blocks * 4 * rm_slot_words() > c->d_partials_cap) {
-        // growing the slot buffer frees the old one: earlier launches must have finished with it
+constexpr size_t RM_Q_HDR = 2 * RM_Q_SHARDS * RM_Q_STRIDE + 64;   // counters, then the three heavy counts on a line of their own
+constexpr uint32_t RM_HEAVY_CAP = 8192;          // heavy-tile list entries kept per frame
+constexpr uint32_t RM_QUEUE_MAX_TILES = 1u << 24;   // beyond this the launch is throughput-bound anyway: no history kept
+
+int ensure_partials(rm_ctx *c, unsigned slots, hipStream_t stream) {
+    size_t bytes = (size_t)slots * 4 * rm_slot_words();
+    if (bytes <= c->d_partials_cap) return RM_OK;
+    // growing the slot buffer frees the old one: earlier launches must have finished with it
+    RM_HIP(c, hipStreamSynchronize(stream));
+    if (c->have_last) RM_HIP(c, hipStreamSynchronize(c->last_stream));
+    return ensure_cap(c, &c->d_partials, &c->d_partials_cap, bytes);
+}
+
+int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream) {
+    const uint32_t tx = (uint32_t)(P.w + 7) / 8, ty = (uint32_t)(P.rows + 7) / 8;
+    const uint32_t n_tiles = tx * ty * (uint32_t)P.n_poses;
+    const int vi = rm_variant_index(P), tab = P.n_prims > 0 ? 1 : 0;
+    if (c->occ[vi][tab] == 0) {
+        int o[2] = {0, 0};
+        RM_HIP(c, rm_launch_queue(P, 0, stream, o));
+        c->occ[vi][0] = o[0] > 0 ? o[0] : 1;
+        c->occ[vi][1] = o[1] > 0 ? o[1] : 1;
+    }
+    const bool keep_history = n_tiles <= RM_QUEUE_MAX_TILES;
+    const uint32_t flag_tiles = keep_history ? n_tiles : 0;
+    if (!c->d_queue || flag_tiles > c->q_tiles_cap) {
         RM_HIP(c, hipStreamSynchronize(stream));
         if (c->have_last) RM_HIP(c, hipStreamSynchronize(c->last_stream));
-        int rc = ensure_cap(c, &c->d_partials, &c->d_partials_cap, (size_t)n_blocks * 4 * rm_slot_words());
+        uint32_t cap_tiles = flag_tiles > c->q_tiles_cap ? flag_tiles : c->q_tiles_cap;
+        size_t words = RM_Q_HDR + 3 * (size_t)RM_HEAVY_CAP + 2 * (size_t)cap_tiles;
+        int rc = ensure_cap(c, &c->d_queue, &c->d_queue_cap, words * 4);
+        if (rc) return rc;
+        RM_HIP(c, hipMemset(c->d_queue, 0, words * 4));
+        c->q_tiles_cap = cap_tiles;
+        c->q_last_mode = -1;                         // history gone
+    }
+    RmQueue &Q = P.queue;
+    Q.counters = c->d_queue;
+    Q.heavy_count = c->d_queue + 2 * RM_Q_SHARDS * RM_Q_STRIDE;
+    Q.heavy_list = c->d_queue + RM_Q_HDR;
+    Q.flags = Q.heavy_list + 3 * (size_t)RM_HEAVY_CAP;
+    Q.n_tiles = n_tiles; Q.tiles_x = tx; Q.tiles_y = ty;
+    {
+        static const uint32_t primes[] = {7919u, 7907u, 7901u, 7883u, 7879u, 7877u, 7873u, 7867u};
+        Q.scatter_mul = 1;
+        if (getf(c, "_RmScatterTiles", 1.0f) != 0.0f)
+            for (uint32_t pr : primes) if (n_tiles % pr != 0) { Q.scatter_mul = pr; break; }
+    }
+    Q.heavy_cap = keep_history ? RM_HEAVY_CAP : 0;
+    float thr = getf(c, "_RmHeavyTileThreshold", 40.0f);
+    Q.heavy_threshold = keep_history && thr > 0.0f ? (uint32_t)thr : 0xffffffffu;
+    const uint32_t e = ++c->q_epoch;
+    Q.epoch = e;
+    Q.use_history = (keep_history && getf(c, "_RmTileFeedback", 1.0f) != 0.0f && c->q_last_mode == P.mode &&
+                     c->q_last_tiles == n_tiles && c->q_last_tx == tx && c->q_last_ty == ty) ? 1u : 0u;
+    Q.cnt_cur = e & 1u; Q.cnt_clr = (e + 1u) & 1u;
+    Q.hv_cur = e % 3u; Q.hv_nxt = (e + 1u) % 3u; Q.hv_clr = (e + 2u) % 3u;
+    Q.fl_cur = e & 1u; Q.fl_nxt = (e + 1u) & 1u;
+    if (!keep_history) { Q.flags = nullptr; }
+    c->q_last_mode = keep_history ? P.mode : -1;
+    c->q_last_tiles = n_tiles; c->q_last_tx = tx; c->q_last_ty = ty;
+
+    unsigned resident = (unsigned)c->n_cus * (unsigned)c->occ[vi][tab];
+    unsigned want = (n_tiles + 3) / 4;
+    unsigned blocks = want < resident ? want : resident;
+    // static share: a fraction of the tiles, dealt evenly over the waves that will not start on a
+    // heavy tile (at most heavy_cap of them do; the kernel uses the exact count)
+    float frac = getf(c, "_RmStaticFraction", 0.7f);
+    frac = frac < 0.0f ? 0.0f : (frac > 1.0f ? 1.0f : frac);
+    Q.static_per_wave = (uint32_t)(frac * (float)n_tiles / (float)(blocks * 4));
+    int rc = ensure_partials(c, blocks * 4, stream);
+    if (rc) return rc;
+    P.partials = c->d_partials;
+    RM_HIP(c, rm_launch_queue(P, blocks, stream, nullptr));
+    c->last_blocks = blocks * 4;
+    return RM_OK;
+}
+
+int launch(rm_ctx *c, const RmParams &U, hipStream_t stream) {
+    RmParams P = U;
+    if (c->kernel == RM_KERNEL_TILE) {
+        unsigned n_blocks = rm_tile_blocks(U.w, U.rows, U.n_poses);
+        int rc = ensure_partials(c, n_blocks, stream);
+        if (rc) return rc;
+        P.partials = c->d_partials;
+        RM_HIP(c, rm_launch_tiles(P, stream));
+        c->last_blocks = n_blocks;
+    } else {
+        int rc = launch_queue(c, P, stream);
         if (rc) return rc;
     }
-    RmParams P = U;
-    P.partials = c->d_partials;
-    RM_HIP(c, rm_launch_tiles(P, stream));
-    c->last_blocks = n_blocks;
     c->last_stream = stream;
     c->last_pixels = (uint64_t)U.w * (uint64_t)U.rows * (uint64_t)U.n_poses;
     c->have_last = true;
@@ -359,6 +448,7 @@ void rm_destroy(rm_ctx *c) {
         if (c->d_views) (void)hipFree(c->d_views);
         if (c->d_stats) (void)hipFree(c->d_stats);
         if (c->d_partials) (void)hipFree(c->d_partials);
+        if (c->d_queue) (void)hipFree(c->d_queue);
         if (c->stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
@@ -436,7 +526,7 @@ int rm_set_primitives(rm_ctx *c, const rm_primitive *prims, int n) {
 
 int rm_set_kernel(rm_ctx *c, int variant) {
     if (!c) return RM_E_ARG;
-    if (variant != RM_KERNEL_AUTO && variant != RM_KERNEL_TILE) return fail(c, RM_E_ARG, "unknown kernel variant");
+    if (variant != RM_KERNEL_AUTO && variant != RM_KERNEL_TILE && variant != RM_KERNEL_QUEUE) return fail(c, RM_E_ARG, "unknown kernel variant");
     c->kernel = variant;
     return RM_OK;
 }

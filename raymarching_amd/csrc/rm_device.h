@@ -45,6 +45,33 @@ struct RmView {
 };
 static_assert(sizeof(RmView) == 64, "RmView layout");
 
+// Tile queue of the persistent kernel and its frame-to-frame state (all device memory owned
+// by the context).  Three heavy-list sets and two counter/flag sets rotate so that a frame
+// never clears anything it, or a concurrently running wave of the same frame, still reads.
+#define RM_Q_SHARDS 8
+#ifndef RM_Q_CHUNK
+#define RM_Q_CHUNK 4          // queue entries per dynamic claim
+#endif
+#ifndef RM_Q_STRIDE
+#define RM_Q_STRIDE 64
+#endif
+//       // words between shard counters: one counter per 256-B line, so shards hit different L2 channels
+struct RmQueue {
+    uint32_t *counters;      // [2][RM_Q_SHARDS][RM_Q_STRIDE] claim counters (first word of each stride)
+    uint32_t *heavy_count;   // [3]
+    uint32_t *heavy_list;    // [3][heavy_cap] tile ids that were expensive in the previous frame
+    uint32_t *flags;         // [2][n_tiles] epoch in which a tile was put on a heavy list
+    uint32_t  n_tiles, tiles_x, tiles_y;
+    uint32_t  heavy_cap, heavy_threshold;
+    uint32_t  scatter_mul;       // coprime with n_tiles
+    uint32_t  static_per_wave;   // entries every wave without a heavy tile takes without claiming
+    uint32_t  epoch;         // this frame's number (monotonic per context)
+    uint32_t  use_history;   // 0: previous frame unusable (first frame, size change)
+    uint32_t  cnt_cur, cnt_clr;          // counter sets: in use / cleared for the next frame
+    uint32_t  hv_cur, hv_nxt, hv_clr;    // heavy sets: read / appended / cleared
+    uint32_t  fl_cur, fl_nxt;            // flag sets: read / written
+};
+
 enum : int32_t { RM_MODE_FRAG = 0, RM_MODE_DEPTH_PERSP = 1, RM_MODE_DEPTH_ORTHO = 2 };
 
 struct RmParams {
@@ -75,6 +102,7 @@ struct RmParams {
     uint8_t  *dst_rgba;
     float    *dst_depth;
     uint8_t  *dst_hit;
-    uint32_t *partials;        // 3 counters per block: n_hit, primary evals, shadow evals
+    uint32_t *partials;        // counter slots (per block or per wave): n_hit, primary evals, shadow evals
+    RmQueue   queue;           // persistent kernel only
     RmPrimDev prims4[4];
 };

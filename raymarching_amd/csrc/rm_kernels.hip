@@ -16,6 +16,9 @@
 #define RM_BWY 2
 #endif
 #define RM_BLOCK (64 * RM_BWX * RM_BWY)
+#ifndef RM_HEAVY_PRIO
+#define RM_HEAVY_PRIO 3
+#endif
 // words per block in the counter-slot buffer; a timeline build (developer tool) appends
 // start/end timestamps of the block (100 MHz s_memrealtime) and its hardware id
 #ifdef RM_TIMELINE
@@ -74,8 +77,88 @@ RM_DI float rm_getshadow(const S &sc, V3 p, V3 n, V3 L, float contact, float dep
     return res;
 }
 
-// One thread = one pixel.  A wave covers an 8x8 pixel tile (neighbouring rays take
-// similar step counts), a 256-thread block a 16x16 tile.  blockIdx.z = pose.
+// The whole fragment program for one pixel (x, local row yl, pose): primary march, and for a
+// hit pixel the six normal taps, the colour evaluation, the shadow march and the shade
+// (shader:149-216).  Miss pixels skip normal/shadow: the shader computes and then discards
+// them (shader:197-202).  Adds this pixel's counts to c_hit / c_p / c_s.
+template <class S>
+RM_DI void rm_shade_pixel(const RmParams &U, const S &sc, int x, int yl, int pose,
+                          unsigned &c_hit, unsigned &c_p, unsigned &c_s) {
+    // compact local row -> frame row (row-band shard; identity when n_parts == 1)
+    const int band = yl / U.band_rows;
+    const int y = (band * U.n_parts + U.part) * U.band_rows + (yl - band * U.band_rows);
+    const size_t gidx = (size_t)y * (size_t)U.w + (size_t)x;                    // full-frame index
+    const size_t oidx = ((size_t)pose * (size_t)U.rows + (size_t)yl) * (size_t)U.w + (size_t)x;
+
+    const RmView &V = U.views ? U.views[pose] : U.view;
+    const float uu = ((float)x + 0.5f) / (float)U.w;
+    const float vv = ((float)y + 0.5f) / (float)U.h;
+    V3 ro, rd;
+    if (U.mode == RM_MODE_DEPTH_ORTHO) {
+        V3 c0 = mk3(U.ortho_c[0][0], U.ortho_c[0][1], U.ortho_c[0][2]);
+        V3 c1 = mk3(U.ortho_c[1][0], U.ortho_c[1][1], U.ortho_c[1][2]);
+        V3 c2 = mk3(U.ortho_c[2][0], U.ortho_c[2][1], U.ortho_c[2][2]);
+        V3 c3 = mk3(U.ortho_c[3][0], U.ortho_c[3][1], U.ortho_c[3][2]);
+        ro = rm_lerp3(rm_lerp3(c3, c2, uu), rm_lerp3(c0, c1, uu), vv);
+        rd = mk3(U.ortho_fwd[0], U.ortho_fwd[1], U.ortho_fwd[2]);
+    } else {
+        // rasteriser interpolation of vert's viewDir (cginc:26-33) to the pixel centre
+        V3 bl = mk3(V.bl[0], V.bl[1], V.bl[2]), br = mk3(V.br[0], V.br[1], V.br[2]);
+        V3 tl = mk3(V.tl[0], V.tl[1], V.tl[2]), tr = mk3(V.tr[0], V.tr[1], V.tr[2]);
+        ro = mk3(rm_vgpr(V.ro[0]), rm_vgpr(V.ro[1]), rm_vgpr(V.ro[2]));
+        rd = rm_lerp3(rm_lerp3(bl, br, uu), rm_lerp3(tl, tr, uu), vv);
+    }
+
+    float depth = U.far_plane;                                    // shader:154
+    if (U.mode == RM_MODE_FRAG && U.sdepth) depth = U.sdepth[gidx];
+    depth = fminf(depth, U.max_dist);                             // cginc:368
+
+    const float sf = rm_vgpr(U.step_factor);
+    MarchResult r = rm_raymarch(sc, ro, rd, depth, U.steps, sf);
+    c_p += (unsigned)r.evals;
+    c_hit += r.hit ? 1u : 0u;
+
+    if (U.mode == RM_MODE_FRAG) {
+        uint32_t rgba;
+        if (r.hit) {
+            const V3 L = mk3(rm_vgpr(U.light[0]), rm_vgpr(U.light[1]), rm_vgpr(U.light[2]));
+            V3 hp = mk3(ro.x + rd.x * r.length, ro.y + rd.y * r.length, ro.z + rd.z * r.length);   // shader:174
+            const float e = U.nss;
+            V3 raw = mk3(sc.w(mk3(hp.x + e, hp.y, hp.z)) - sc.w(mk3(hp.x - e, hp.y, hp.z)),        // shader:63-67
+                         sc.w(mk3(hp.x, hp.y + e, hp.z)) - sc.w(mk3(hp.x, hp.y - e, hp.z)),
+                         sc.w(mk3(hp.x, hp.y, hp.z + e)) - sc.w(mk3(hp.x, hp.y, hp.z - e)));
+            V3 n = rm_normalize(raw);
+            V4 s = sc.full(hp);                                                                   // shader:193
+            int sev = 0;
+            float sh = rm_getshadow(sc, hp, n, L, r.contact, U.shadow_depth, U.steps, sf, sev);
+            c_s += (unsigned)sev;
+            float shadow = sh * 0.75f + .25f;                        // remap(x,0,1,.25,1), cginc:80-82
+            float ndl = rm_dot3(n, L) * .5f + .5f;
+            float ao = rm_clamp01(rm_len3(mk3(raw.x / U.nss_raw, raw.y / U.nss_raw, raw.z / U.nss_raw)));  // shader:125-127
+            float cr = ((s.x * ndl) * shadow) * ao;
+            float cg = ((s.y * ndl) * shadow) * ao;
+            float cb = ((s.z * ndl) * shadow) * ao;
+            rgba = rm_unorm8(cr) | (rm_unorm8(cg) << 8) | (rm_unorm8(cb) << 16) | 0xFF000000u;
+        } else if (U.src) {
+            rgba = reinterpret_cast<const uint32_t *>(U.src)[gidx] | 0xFF000000u;
+        } else {
+            rgba = U.bg_rgba8;
+        }
+        if (U.dst_rgba) reinterpret_cast<uint32_t *>(U.dst_rgba)[oidx] = rgba;
+    }
+    if (U.dst_depth) U.dst_depth[oidx] = r.length;
+    if (U.dst_hit) U.dst_hit[oidx] = r.hit ? 1 : 0;
+}
+
+RM_DI unsigned rm_wave_sum(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---- kernel A: one launch block per image tile -------------------------------------------
+// One thread = one pixel.  A wave covers an 8x8 pixel tile (neighbouring rays take similar
+// step counts), a block RM_BWX x RM_BWY such tiles.  blockIdx.z = pose.
 template <class S>
 RM_DI void rm_pixel(const RmParams &U, const S &sc) {
     __shared__ unsigned int s_cnt[3];
@@ -86,94 +169,15 @@ RM_DI void rm_pixel(const RmParams &U, const S &sc) {
 #ifdef RM_TIMELINE
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
 #endif
-
     const int lane = tid & 63, wv = tid >> 6;
     const int x  = blockIdx.x * (8 * RM_BWX) + (wv % RM_BWX) * 8 + (lane & 7);
-#ifdef RM_EXPERIMENT_ROWSHIFT
-    const int by_ = (int)((blockIdx.y + (unsigned)RM_EXPERIMENT_ROWSHIFT) % gridDim.y);
-#else
-    const int by_ = (int)blockIdx.y;
-#endif
-    const int yl = by_ * (8 * RM_BWY) + (wv / RM_BWX) * 8 + (lane >> 3);
-    const int pose = blockIdx.z;
-    const bool valid = x < U.w && yl < U.rows;
-
-    if (valid) {
-        // compact local row -> frame row (row-band shard; identity when n_parts == 1)
-        const int band = yl / U.band_rows;
-        const int y = (band * U.n_parts + U.part) * U.band_rows + (yl - band * U.band_rows);
-        const size_t gidx = (size_t)y * (size_t)U.w + (size_t)x;                    // full-frame index
-        const size_t oidx = ((size_t)pose * (size_t)U.rows + (size_t)yl) * (size_t)U.w + (size_t)x;
-
-        const RmView &V = U.views ? U.views[pose] : U.view;
-        const float uu = ((float)x + 0.5f) / (float)U.w;
-        const float vv = ((float)y + 0.5f) / (float)U.h;
-        V3 ro, rd;
-        if (U.mode == RM_MODE_DEPTH_ORTHO) {
-            V3 c0 = mk3(U.ortho_c[0][0], U.ortho_c[0][1], U.ortho_c[0][2]);
-            V3 c1 = mk3(U.ortho_c[1][0], U.ortho_c[1][1], U.ortho_c[1][2]);
-            V3 c2 = mk3(U.ortho_c[2][0], U.ortho_c[2][1], U.ortho_c[2][2]);
-            V3 c3 = mk3(U.ortho_c[3][0], U.ortho_c[3][1], U.ortho_c[3][2]);
-            ro = rm_lerp3(rm_lerp3(c3, c2, uu), rm_lerp3(c0, c1, uu), vv);
-            rd = mk3(U.ortho_fwd[0], U.ortho_fwd[1], U.ortho_fwd[2]);
-        } else {
-            // rasteriser interpolation of vert's viewDir (cginc:26-33) to the pixel centre
-            V3 bl = mk3(V.bl[0], V.bl[1], V.bl[2]), br = mk3(V.br[0], V.br[1], V.br[2]);
-            V3 tl = mk3(V.tl[0], V.tl[1], V.tl[2]), tr = mk3(V.tr[0], V.tr[1], V.tr[2]);
-            ro = mk3(rm_vgpr(V.ro[0]), rm_vgpr(V.ro[1]), rm_vgpr(V.ro[2]));
-            rd = rm_lerp3(rm_lerp3(bl, br, uu), rm_lerp3(tl, tr, uu), vv);
-        }
-
-        float depth = U.far_plane;                                    // shader:154
-        if (U.mode == RM_MODE_FRAG && U.sdepth) depth = U.sdepth[gidx];
-        depth = fminf(depth, U.max_dist);                             // cginc:368
-
-        const float sf = rm_vgpr(U.step_factor);
-        MarchResult r = rm_raymarch(sc, ro, rd, depth, U.steps, sf);
-        c_p = (unsigned)r.evals;
-        c_hit = r.hit ? 1u : 0u;
-
-        if (U.mode == RM_MODE_FRAG) {
-            uint32_t rgba;
-            if (r.hit) {
-                const V3 L = mk3(rm_vgpr(U.light[0]), rm_vgpr(U.light[1]), rm_vgpr(U.light[2]));
-                V3 hp = mk3(ro.x + rd.x * r.length, ro.y + rd.y * r.length, ro.z + rd.z * r.length);   // shader:174
-                const float e = U.nss;
-                V3 raw = mk3(sc.w(mk3(hp.x + e, hp.y, hp.z)) - sc.w(mk3(hp.x - e, hp.y, hp.z)),        // shader:63-67
-                             sc.w(mk3(hp.x, hp.y + e, hp.z)) - sc.w(mk3(hp.x, hp.y - e, hp.z)),
-                             sc.w(mk3(hp.x, hp.y, hp.z + e)) - sc.w(mk3(hp.x, hp.y, hp.z - e)));
-                V3 n = rm_normalize(raw);
-                V4 s = sc.full(hp);                                                                   // shader:193
-                int sev = 0;
-                float sh = rm_getshadow(sc, hp, n, L, r.contact, U.shadow_depth, U.steps, sf, sev);
-                c_s = (unsigned)sev;
-                float shadow = sh * 0.75f + .25f;                        // remap(x,0,1,.25,1), cginc:80-82
-                float ndl = rm_dot3(n, L) * .5f + .5f;
-                float ao = rm_clamp01(rm_len3(mk3(raw.x / U.nss_raw, raw.y / U.nss_raw, raw.z / U.nss_raw)));  // shader:125-127
-                float cr = ((s.x * ndl) * shadow) * ao;
-                float cg = ((s.y * ndl) * shadow) * ao;
-                float cb = ((s.z * ndl) * shadow) * ao;
-                rgba = rm_unorm8(cr) | (rm_unorm8(cg) << 8) | (rm_unorm8(cb) << 16) | 0xFF000000u;
-            } else if (U.src) {
-                rgba = reinterpret_cast<const uint32_t *>(U.src)[gidx] | 0xFF000000u;
-            } else {
-                rgba = U.bg_rgba8;
-            }
-            if (U.dst_rgba) reinterpret_cast<uint32_t *>(U.dst_rgba)[oidx] = rgba;
-        }
-        if (U.dst_depth) U.dst_depth[oidx] = r.length;
-        if (U.dst_hit) U.dst_hit[oidx] = r.hit ? 1 : 0;
-    }
+    const int yl = blockIdx.y * (8 * RM_BWY) + (wv / RM_BWX) * 8 + (lane >> 3);
+    if (x < U.w && yl < U.rows) rm_shade_pixel(U, sc, x, yl, (int)blockIdx.z, c_hit, c_p, c_s);
 
     // Counters: per-wave sums by cross-lane shuffles, per-block sums in LDS, then ONE plain
     // store per counter into this block's own slot.  No global atomics: same-address atomics
-    // from thousands of short blocks serialise in L2 (~6 ns each) and would bound the frame.
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        c_hit += __shfl_xor(c_hit, o);
-        c_p += __shfl_xor(c_p, o);
-        c_s += __shfl_xor(c_s, o);
-    }
+    // from thousands of short blocks serialise in L2 (~5 ns each) and would bound the frame.
+    c_hit = rm_wave_sum(c_hit); c_p = rm_wave_sum(c_p); c_s = rm_wave_sum(c_s);
     if (lane == 0) {
         if (c_hit) atomicAdd(&s_cnt[0], c_hit);
         if (c_p) atomicAdd(&s_cnt[1], c_p);
@@ -181,19 +185,156 @@ RM_DI void rm_pixel(const RmParams &U, const S &sc) {
     }
     __syncthreads();
     if (tid < 3) {
-        const unsigned bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;   // slot by launch index, not by image position
+        const unsigned bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         U.partials[RM_SLOT_WORDS * bid + tid] = s_cnt[tid];
 #ifdef RM_TIMELINE
         if (tid == 0) {
             const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
-            unsigned hwid;
+            unsigned hwid, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             unsigned *o = U.partials + RM_SLOT_WORDS * bid;
             o[3] = (unsigned)t_start; o[4] = (unsigned)(t_start >> 32); o[5] = (unsigned)t_end; o[6] = (unsigned)(t_end >> 32);
             o[7] = (hwid & 0xffffu) | (xcc << 16);
         }
+#endif
+    }
+}
+
+// ---- kernel B: persistent waves pulling 8x8 tiles from an ordered queue --------------------
+// The grid is sized to what the chip holds at once; every wave loops: claim a queue entry,
+// render that tile, claim the next.  The queue lists the tiles that were expensive in the
+// previous frame of this context first (RmQueue::heavy_*), then all tiles in image order,
+// skipping the ones already listed.  A frame's critical path is its most expensive tile (a
+// few hundred dependent scene evaluations); starting those tiles at t = 0 hides them behind
+// the bulk of cheap tiles instead of leaving them as a tail.  Each tile is rendered exactly
+// once whatever the order, so the image does not depend on the history.
+//
+// Claims are atomic adds on RM_Q_SHARDS counters (entries interleaved over the shards, a wave
+// starts on shard = block index mod RM_Q_SHARDS and moves on when its shard runs dry); the
+// next claim is issued before the current tile is rendered so its latency is hidden.
+template <class S>
+RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
+    const RmQueue &Q = U.queue;
+    const int lane = threadIdx.x & 63;
+    const unsigned gw = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);   // global wave id, wave-uniform
+    unsigned c_hit = 0, c_p = 0, c_s = 0;
+#ifdef RM_TIMELINE
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+    unsigned n_done = 0, max_cost = 0;
+#endif
+
+    // frame-to-frame state: this frame reads set `cur`, appends to `nxt`, clears `clr`
+    if (gw == 0 && lane < RM_Q_SHARDS) Q.counters[(Q.cnt_clr * RM_Q_SHARDS + lane) * RM_Q_STRIDE] = 0u;
+    if (gw == 0 && lane == 0) Q.heavy_count[Q.hv_clr] = 0u;
+
+    unsigned n_heavy = 0;
+    if (Q.use_history) {
+        n_heavy = Q.heavy_count[Q.hv_cur];
+        n_heavy = n_heavy < Q.heavy_cap ? n_heavy : Q.heavy_cap;
+    }
+    n_heavy = __builtin_amdgcn_readfirstlane(n_heavy);
+    const unsigned n_entries = n_heavy + Q.n_tiles;
+    const unsigned *heavy_cur = Q.heavy_list + (size_t)Q.hv_cur * Q.heavy_cap;
+    unsigned *heavy_nxt = Q.heavy_list + (size_t)Q.hv_nxt * Q.heavy_cap;
+    const unsigned *flag_cur = Q.flags + (size_t)Q.fl_cur * Q.n_tiles;
+    unsigned *flag_nxt = Q.flags + (size_t)Q.fl_nxt * Q.n_tiles;
+    unsigned *counters = Q.counters + Q.cnt_cur * RM_Q_SHARDS * RM_Q_STRIDE;
+
+    // Queue layout: [heavy tiles of the previous frame][static part][dynamic part].
+    //  * wave w < n_heavy starts with heavy entry w, the other waves with their static share:
+    //    every wave begins at t = 0 without touching a counter, and each expensive tile gets
+    //    a wave of its own;
+    //  * the static part (Q.static_per_wave entries per non-heavy wave, dealt cyclically) covers
+    //    most of the frame without atomics: a device-scope returning atomic is a memory-side
+    //    operation here (~1-3 us, ~90 per us and word), far too slow to claim every 3-us tile;
+    //  * the dynamic part is claimed RM_Q_CHUNK entries at a time from RM_Q_SHARDS counters, each on
+    //    its own 256-B line, by waves that have run out of static work -- it evens out what
+    //    the static deal left unbalanced.  The claim for the next entry is issued before the
+    //    current tile is rendered.
+    const unsigned n_waves = (gridDim.x * blockDim.x) >> 6;
+    const unsigned n_static_waves = n_waves > n_heavy ? n_waves - n_heavy : 0u;
+    const unsigned static_end = n_heavy + Q.static_per_wave * n_static_waves;      // <= n_entries by construction
+    unsigned shard = blockIdx.x % RM_Q_SHARDS, tried = 0;
+    unsigned static_left = gw >= n_heavy ? Q.static_per_wave : 0u;
+    unsigned static_next = n_heavy + (gw - n_heavy);
+    unsigned dyn_left = 0, dyn_next = 0;
+    auto claim = [&]() -> unsigned {
+        // returns an entry index, or 0xffffffff when the queue is exhausted
+        if (static_left) {
+            unsigned e = static_next;
+            static_next += n_static_waves;
+            static_left--;
+            return e;
+        }
+        if (dyn_left) { dyn_left--; return dyn_next++; }
+        unsigned e = 0xffffffffu;
+        while (tried < RM_Q_SHARDS) {
+            // a dry shard is recognised by a plain load before spending an atomic on it
+            unsigned k = __hip_atomic_load(&counters[shard * RM_Q_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            k = __builtin_amdgcn_readfirstlane(k);
+            if (static_end + (k * RM_Q_SHARDS + shard) * RM_Q_CHUNK < n_entries) {
+                if (lane == 0) k = atomicAdd(&counters[shard * RM_Q_STRIDE], 1u);
+                k = __builtin_amdgcn_readfirstlane(k);
+                unsigned first = static_end + (k * RM_Q_SHARDS + shard) * RM_Q_CHUNK;
+                if (first < n_entries) {
+                    unsigned last = first + RM_Q_CHUNK < n_entries ? first + RM_Q_CHUNK : n_entries;
+                    e = first; dyn_next = first + 1; dyn_left = last - first - 1;
+                    break;
+                }
+            }
+            shard = (shard + 1) % RM_Q_SHARDS;
+            tried++;
+        }
+        return e;
+    };
+
+    unsigned nxt = gw < n_heavy ? gw : claim();
+    while (nxt != 0xffffffffu) {
+        const unsigned cur = nxt;
+        nxt = claim();
+        unsigned tile;
+        // A tile from the heavy list is a long dependent chain that the frame cannot end before:
+        // its wave gets issue priority over the waves that render cheap tiles on the same SIMD.
+        if (cur < n_heavy) __builtin_amdgcn_s_setprio(RM_HEAVY_PRIO); else __builtin_amdgcn_s_setprio(0);
+        if (cur < n_heavy) {
+            tile = heavy_cur[cur];
+        } else {
+            // image-order position -> tile through a fixed bijection (multiplication by a number
+            // coprime with n_tiles): the tiles one wave gets from its cyclic static share are
+            // scattered over the image instead of lining up in one image column
+            tile = (unsigned)(((unsigned long long)(cur - n_heavy) * Q.scatter_mul) % Q.n_tiles);
+            if (Q.use_history && flag_cur[tile] == Q.epoch) continue;       // rendered through the heavy list
+        }
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        const unsigned per_pose = Q.tiles_x * Q.tiles_y;
+        const unsigned pose = tile / per_pose, t2 = tile - pose * per_pose;
+        const unsigned ty = t2 / Q.tiles_x, tx = t2 - ty * Q.tiles_x;
+        const int x = (int)(tx * 8u) + (lane & 7), yl = (int)(ty * 8u) + (lane >> 3);
+        unsigned t_hit = 0, t_p = 0, t_s = 0;
+        if (x < U.w && yl < U.rows) rm_shade_pixel(U, sc, x, yl, (int)pose, t_hit, t_p, t_s);
+        c_hit += t_hit; c_p += t_p; c_s += t_s;
+        // cost of this tile for the wave = its longest pixel; remember expensive tiles for the next frame
+        unsigned cost = t_p + t_s + (t_hit ? 7u : 0u);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { unsigned v = __shfl_xor(cost, o); cost = cost > v ? cost : v; }
+#ifdef RM_TIMELINE
+        n_done++; max_cost = max_cost > cost ? max_cost : cost;
+#endif
+        if (cost >= Q.heavy_threshold && lane == 0) {
+            unsigned idx = atomicAdd(&Q.heavy_count[Q.hv_nxt], 1u);
+            if (idx < Q.heavy_cap) { heavy_nxt[idx] = tile; flag_nxt[tile] = Q.epoch + 1u; }
+        }
+    }
+
+    c_hit = rm_wave_sum(c_hit); c_p = rm_wave_sum(c_p); c_s = rm_wave_sum(c_s);
+    if (lane == 0) {
+        unsigned *o = U.partials + RM_SLOT_WORDS * gw;
+        o[0] = c_hit; o[1] = c_p; o[2] = c_s;
+#ifdef RM_TIMELINE
+        const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+        o[3] = (unsigned)t_start; o[4] = (unsigned)(t_start >> 32); o[5] = (unsigned)t_end; o[6] = (unsigned)(t_end >> 32);
+        o[7] = n_done | (max_cost << 16);
 #endif
     }
 }
@@ -230,6 +371,34 @@ __global__ RM_LB void rm_tile_kernelN(const RmParams U) {
 }
 
 template <bool ROT, int SCL>
+__global__ __launch_bounds__(256) void rm_queue_kernel4(const RmParams U) {
+    Scene4<ROT, SCL> sc(U);
+    rm_queue_body(U, sc);
+}
+
+template <bool ROT, int SCL>
+__global__ __launch_bounds__(256) void rm_queue_kernelN(const RmParams U) {
+    SceneN<ROT, SCL> sc(U.prim_table, U.n_prims);
+    rm_queue_body(U, sc);
+}
+
+template <bool ROT, int SCL>
+hipError_t launch_queue_variant(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu) {
+    if (blocks_per_cu) {
+        int n4 = 0, nN = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, rm_queue_kernel4<ROT, SCL>, 256, 0);
+        if (e != hipSuccess) return e;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nN, rm_queue_kernelN<ROT, SCL>, 256, 0);
+        if (e != hipSuccess) return e;
+        blocks_per_cu[0] = n4; blocks_per_cu[1] = nN;
+        return hipSuccess;
+    }
+    if (U.n_prims > 0) hipLaunchKernelGGL((rm_queue_kernelN<ROT, SCL>), dim3(blocks), dim3(256), 0, stream, U);
+    else               hipLaunchKernelGGL((rm_queue_kernel4<ROT, SCL>), dim3(blocks), dim3(256), 0, stream, U);
+    return hipGetLastError();
+}
+
+template <bool ROT, int SCL>
 hipError_t launch_variant(const RmParams &U, dim3 grid, hipStream_t stream) {
     if (U.n_prims > 0) hipLaunchKernelGGL((rm_tile_kernelN<ROT, SCL>), grid, dim3(RM_BLOCK), 0, stream, U);
     else               hipLaunchKernelGGL((rm_tile_kernel4<ROT, SCL>), grid, dim3(RM_BLOCK), 0, stream, U);
@@ -248,6 +417,28 @@ hipError_t rm_reduce_stats(const unsigned *partials, unsigned n_blocks, unsigned
     hipLaunchKernelGGL(rm_reduce_stats_kernel, dim3(1), dim3(1024), 0, stream, partials, n_blocks, out);
     return hipGetLastError();
 }
+
+// variant index 0..5 = (rot ? 3 : 0) + scl
+static int variant_index(const RmParams &U, bool &rot, int &scl) {
+    rot = !(U.scene_flags & RM_SF_IDENT_ROT);
+    scl = (U.scene_flags & RM_SF_UNIT_SCALE) ? RM_SCL_UNIT : (U.scene_flags & RM_SF_RCP) ? RM_SCL_RCP : RM_SCL_DIV;
+    return (rot ? 3 : 0) + scl;
+}
+
+hipError_t rm_launch_queue(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu) {
+    bool rot; int scl;
+    variant_index(U, rot, scl);
+    if (rot) {
+        if (scl == RM_SCL_UNIT) return launch_queue_variant<true, RM_SCL_UNIT>(U, blocks, stream, blocks_per_cu);
+        if (scl == RM_SCL_RCP)  return launch_queue_variant<true, RM_SCL_RCP>(U, blocks, stream, blocks_per_cu);
+        return launch_queue_variant<true, RM_SCL_DIV>(U, blocks, stream, blocks_per_cu);
+    }
+    if (scl == RM_SCL_UNIT) return launch_queue_variant<false, RM_SCL_UNIT>(U, blocks, stream, blocks_per_cu);
+    if (scl == RM_SCL_RCP)  return launch_queue_variant<false, RM_SCL_RCP>(U, blocks, stream, blocks_per_cu);
+    return launch_queue_variant<false, RM_SCL_DIV>(U, blocks, stream, blocks_per_cu);
+}
+
+int rm_variant_index(const RmParams &U) { bool r; int s; return variant_index(U, r, s); }
 
 hipError_t rm_launch_tiles(const RmParams &U, hipStream_t stream) {
     if (U.w <= 0 || U.rows <= 0 || U.n_poses <= 0) return hipErrorInvalidValue;

@@ -4,7 +4,7 @@
 #include "rm_device.h"
 
 // kernel variants selectable through rm_set_kernel()
-enum { RM_KERNEL_AUTO = 0, RM_KERNEL_TILE = 1 };
+enum { RM_KERNEL_AUTO = 0, RM_KERNEL_TILE = 1, RM_KERNEL_QUEUE = 2 };
 
 // one-thread-per-pixel tile kernel over U.w x U.rows x U.n_poses
 hipError_t rm_launch_tiles(const RmParams &U, hipStream_t stream);
@@ -15,3 +15,9 @@ unsigned rm_slot_words();
 unsigned rm_tile_blocks(int w, int rows, int n_poses);
 // sums n_blocks counter slots into out[0..2] (device memory)
 hipError_t rm_reduce_stats(const unsigned *partials, unsigned n_blocks, unsigned long long *out, hipStream_t stream);
+
+// persistent tile-queue kernel: `blocks` workgroups of 256 threads.  With blocks_per_cu != nullptr
+// nothing is launched; blocks_per_cu[0..1] receive the resident blocks per CU of the 4-slot and
+// the table variant that U selects.
+hipError_t rm_launch_queue(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu);
+int rm_variant_index(const RmParams &U);

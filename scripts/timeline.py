@@ -7,6 +7,8 @@ from raymarching_amd import Material, Raymarching, RenderTexture, scenes
 w, h = int(sys.argv[1]) if len(sys.argv) > 1 else 1920, int(sys.argv[2]) if len(sys.argv) > 2 else 1080
 mat = Material(); rm = Raymarching(scenes.default_camera(w, h), mat, scenes.default_transforms())
 mat.SetVector("_WorldSpaceLightPos0", scenes.WORLD_SPACE_LIGHT_POS0)
+mat.set_kernel(int(os.environ.get("RM_KERNEL", "0")))
+mat.SetFloat("_RmStaticFraction", float(os.environ.get("RM_FRAC", "0.7")))
 rt = RenderTexture(w, h, device="cuda:0")
 for _ in range(20): rm.OnRenderImage(None, rt)
 torch.cuda.synchronize()
@@ -26,6 +28,10 @@ print("block duration us: mean %.2f  p50 %.2f  p99 %.2f  max %.2f" % (dur.mean()
 i = int(np.argmax(en)); print("last block to end: id %d start %.1f end %.1f evals p/s %d/%d" % (i, st[i], en[i], s[i, 1], s[i, 2]))
 j = np.argsort(dur)[::-1][:8]
 for b in j: print("  long block id %6d (row %3d col %3d) start %6.1f end %6.1f dur %6.1f" % (b, b // ((w + 15) // 16), b % ((w + 15) // 16), st[b], en[b], dur[b]))
+print("per-slot tiles done: mean %.1f max %d; max tile cost seen %d" % ((s[:,7]&0xffff).mean(), (s[:,7]&0xffff).max(), (s[:,7]>>16).max()))
+print("wave end-time percentiles 10/50/90/99/100:", np.round(np.percentile(en,[10,50,90,99,100]),1))
+hv=(s[:,7]>>16)>=40
+print("waves that saw a heavy tile:", int(hv.sum()), "their end times p50/max: %.1f %.1f" % (np.median(en[hv]), en[hv].max()), "; others p50/max: %.1f %.1f" % (np.median(en[~hv]), en[~hv].max()))
 edges = np.arange(0, en.max() + 5, 5.0)
 resident = [(int(((st <= t) & (en > t)).sum())) for t in edges]
 print("resident blocks every 5 us:", resident)

@@ -27,12 +27,26 @@ def torch_cuda():
     return torch
 
 
-def gpu_run(case, torch, host_path=False):
-    """binds the case and renders it through the C ABI (device pointers unless host_path)"""
+KERNELS = {"tile": 1, "queue": 2}
+
+
+def gpu_run(case, torch, host_path=False, kernel=0, frames=1):
+    """binds the case and renders it through the C ABI (device pointers unless host_path);
+    `frames` > 1 re-renders into the same target (exercises the frame-to-frame tile history)"""
     from raymarching_amd import Graphics, Material, RenderTexture
     from raymarching_amd.material import _fp, _ptr, current_stream_handle
     with Material() as mat:
+        mat.set_kernel(kernel)
         src, sd = case.bind(mat)
+        for _ in range(frames - 1):
+            _render_once(case, torch, mat, src, sd, host_path)
+        return _render_once(case, torch, mat, src, sd, host_path)
+
+
+def _render_once(case, torch, mat, src, sd, host_path):
+    from raymarching_amd import Graphics, RenderTexture
+    from raymarching_amd.material import _fp, _ptr, current_stream_handle
+    if True:
         dev = None if host_path else "cuda:0"
         rt = RenderTexture(case.w, case.h, device=dev)
         lib, h = mat._lib, mat.handle
@@ -69,11 +83,12 @@ def gpu_run(case, torch, host_path=False):
         return {"rgba": rt.color.cpu().numpy(), "depth": rt.depth.cpu().numpy(), "hit": rt.hit.cpu().numpy(), "stats": st}
 
 
+@pytest.mark.parametrize("kernel", ["tile", "queue"])
 @pytest.mark.parametrize("name", [c.name for c in cases.CASES if not c.heavy])
-def test_gpu_equals_oracle(oracle, torch_cuda, name):
+def test_gpu_equals_oracle(oracle, torch_cuda, name, kernel):
     case = cases.BY_NAME[name]
     ref = cases.oracle_run(case, oracle)
-    got = gpu_run(case, torch_cuda)
+    got = gpu_run(case, torch_cuda, kernel=KERNELS[kernel])
     if case.kind == "frag":
         assert_frame_equal(got, ref, name)
         assert got["stats"]["sum_steps_s"] == ref["stats"]["sum_steps_s"]
@@ -85,11 +100,14 @@ def test_gpu_equals_oracle(oracle, torch_cuda, name):
     assert got["stats"]["n_pixels"] == case.w * case.h
 
 
+@pytest.mark.parametrize("kernel,frames", [("tile", 1), ("queue", 1), ("queue", 4)])
 @pytest.mark.parametrize("name", ["default_1920x1080", "default_3840x2160"])
-def test_gpu_full_size_matches_golden_hashes(torch_cuda, name):
-    """BASELINE sizes (1080p, 4K) against the oracle's committed hashes"""
+def test_gpu_full_size_matches_golden_hashes(torch_cuda, name, kernel, frames):
+    """BASELINE sizes (1080p, 4K) against the oracle's committed hashes; with frames > 1 the
+    persistent kernel orders its tile queue by the previous frame's costs, which must not
+    change a single output byte"""
     case, g = cases.BY_NAME[name], GOLD[name]
-    got = gpu_run(case, torch_cuda)
+    got = gpu_run(case, torch_cuda, kernel=KERNELS[kernel], frames=frames)
     assert sha(got["hit"]) == g["sha_hit"]
     assert sha(got["depth"]) == g["sha_depth"]
     assert sha(got["rgba"]) == g["sha_rgba"]
@@ -178,6 +196,26 @@ def test_pose_batch_equals_single_blits(oracle, torch_cuda):
             assert torch.equal(d[i].view(torch.int32), singles[i].depth.view(torch.int32))
     ref = cases.oracle_run(cases.BY_NAME["orbit_k23_480x270"], oracle)
     assert np.array_equal(c[2].cpu().numpy(), ref["rgba"])
+
+
+@pytest.mark.parametrize("name", ["stress256_320x180", "orbit_k23_480x270", "shadow_dir_256x144"])
+def test_tile_history_does_not_change_output(oracle, torch_cuda, name):
+    """3rd consecutive frame (heavy tiles first) == 1st frame == oracle, also with a very low threshold"""
+    from raymarching_amd import Material
+    case = cases.BY_NAME[name]
+    ref = cases.oracle_run(case, oracle)
+    for thr in (40.0, 3.0):
+        with Material() as mat:
+            mat.set_kernel(KERNELS["queue"])
+            src, sd = case.bind(mat)
+            mat.SetFloat("_RmHeavyTileThreshold", thr)
+            for _ in range(3):
+                got = _render_once(case, torch_cuda, mat, src, sd, False)
+                assert np.array_equal(got["depth"].view(np.uint32), ref["depth"].view(np.uint32))
+                assert np.array_equal(got["hit"], ref["hit"])
+                if case.kind == "frag":
+                    assert np.array_equal(got["rgba"], ref["rgba"])
+                assert got["stats"]["sum_steps_p"] == ref["stats"]["sum_steps_p"]
 
 
 def test_repeat_runs_are_identical_and_counters_reset(torch_cuda):
