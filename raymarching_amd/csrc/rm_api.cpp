@@ -63,8 +63,8 @@ struct rm_ctx {
     size_t d_stage_cap[5] = {0, 0, 0, 0, 0};
 
     // persistent-kernel queue state (see RmQueue)
-    uint32_t *d_queue = nullptr; size_t d_queue_cap = 0;   // counters | heavy_count | heavy_list | flags
-    uint32_t q_tiles_cap = 0;      // flags capacity in tiles
+    uint32_t *d_queue = nullptr; size_t d_queue_cap = 0;   // counters | heavy_count | heavy_list | bitmaps
+    uint32_t q_bm_cap = 0;         // capacity of one heavy bitmap in words
     uint32_t q_epoch = 0;
     uint32_t q_last_tiles = 0, q_last_tx = 0, q_last_ty = 0; int q_last_mode = -1;
     int n_cus = 0;
@@ -268,7 +268,10 @@ int build_params(rm_ctx *c, RmParams *U, hipStream_t stream) {
     U->light[0] = L[0]; U->light[1] = L[1]; U->light[2] = L[2];          // float4 -> float3 (shader:109)
     float max_steps = getf(c, "_MaxSteps", 100.0f);
     float max_dist = getf(c, "_MaxDist", 100.0f);
-    U->steps = std::fmin(2000.0f, max_steps);
+    {
+        float steps = std::fmin(2000.0f, max_steps);          // (float)i < steps  <=>  i < ceil(steps) for integer i >= 0
+        U->n_steps = steps > 0.0f ? (int32_t)std::ceil(steps) : 0;
+    }
     U->max_dist = max_dist;
     U->shadow_depth = std::fmin(2000.0f, max_dist);
     U->far_plane = getv(c, "_ProjectionParams")[2];
@@ -325,7 +328,7 @@ int check_size(rm_ctx *c, int w, int h) {
 
 constexpr size_t RM_Q_HDR = 2 * RM_Q_SHARDS * RM_Q_STRIDE + 64;   // counters, then the three heavy counts on a line of their own
 constexpr uint32_t RM_HEAVY_CAP = 8192;          // heavy-tile list entries kept per frame
-constexpr uint32_t RM_QUEUE_MAX_TILES = 1u << 24;   // beyond this the launch is throughput-bound anyway: no history kept
+constexpr uint32_t RM_QUEUE_MAX_TILES = 160u * 1024u;   // 20 KB of LDS bitmap per block at most (4K frame = 129600 tiles)
 
 int ensure_partials(rm_ctx *c, unsigned slots, hipStream_t stream) {
     size_t bytes = (size_t)slots * 4 * rm_slot_words();
@@ -346,42 +349,48 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream) {
         c->occ[vi][0] = o[0] > 0 ? o[0] : 1;
         c->occ[vi][1] = o[1] > 0 ? o[1] : 1;
     }
+    // the heavy bitmap lives in LDS: keep history only while it fits comfortably beside 4+ blocks per CU
     const bool keep_history = n_tiles <= RM_QUEUE_MAX_TILES;
-    const uint32_t flag_tiles = keep_history ? n_tiles : 0;
-    if (!c->d_queue || flag_tiles > c->q_tiles_cap) {
+    const uint32_t bm_words = keep_history ? (n_tiles + 31) / 32 : 0;
+    if (!c->d_queue || bm_words > c->q_bm_cap) {
         RM_HIP(c, hipStreamSynchronize(stream));
         if (c->have_last) RM_HIP(c, hipStreamSynchronize(c->last_stream));
-        uint32_t cap_tiles = flag_tiles > c->q_tiles_cap ? flag_tiles : c->q_tiles_cap;
-        size_t words = RM_Q_HDR + 3 * (size_t)RM_HEAVY_CAP + 2 * (size_t)cap_tiles;
+        uint32_t cap = bm_words > c->q_bm_cap ? bm_words : c->q_bm_cap;
+        if (cap < 64) cap = 64;
+        size_t words = RM_Q_HDR + 3 * (size_t)RM_HEAVY_CAP + 3 * (size_t)cap;
         int rc = ensure_cap(c, &c->d_queue, &c->d_queue_cap, words * 4);
         if (rc) return rc;
         RM_HIP(c, hipMemset(c->d_queue, 0, words * 4));
-        c->q_tiles_cap = cap_tiles;
+        c->q_bm_cap = cap;
         c->q_last_mode = -1;                         // history gone
     }
     RmQueue &Q = P.queue;
     Q.counters = c->d_queue;
     Q.heavy_count = c->d_queue + 2 * RM_Q_SHARDS * RM_Q_STRIDE;
     Q.heavy_list = c->d_queue + RM_Q_HDR;
-    Q.flags = Q.heavy_list + 3 * (size_t)RM_HEAVY_CAP;
+    Q.bitmaps = Q.heavy_list + 3 * (size_t)RM_HEAVY_CAP;
     Q.n_tiles = n_tiles; Q.tiles_x = tx; Q.tiles_y = ty;
+    const bool same_shape = c->q_last_mode == P.mode && c->q_last_tiles == n_tiles && c->q_last_tx == tx && c->q_last_ty == ty;
+    if (keep_history && !same_shape && c->q_last_mode != -1) {
+        // the three bitmap sets were laid out for another tile count: start clean
+        RM_HIP(c, hipStreamSynchronize(stream));
+        if (c->have_last) RM_HIP(c, hipStreamSynchronize(c->last_stream));
+        RM_HIP(c, hipMemset(c->d_queue, 0, c->d_queue_cap));
+    }
+    Q.bitmap_words = bm_words;
     {
         static const uint32_t primes[] = {7919u, 7907u, 7901u, 7883u, 7879u, 7877u, 7873u, 7867u};
         Q.scatter_mul = 1;
         if (getf(c, "_RmScatterTiles", 1.0f) != 0.0f)
             for (uint32_t pr : primes) if (n_tiles % pr != 0) { Q.scatter_mul = pr; break; }
     }
-    Q.heavy_cap = keep_history ? RM_HEAVY_CAP : 0;
-    float thr = getf(c, "_RmHeavyTileThreshold", 40.0f);
+    Q.heavy_cap = RM_HEAVY_CAP;
+    float thr = getf(c, "_RmHeavyTileThreshold", 24.0f);
     Q.heavy_threshold = keep_history && thr > 0.0f ? (uint32_t)thr : 0xffffffffu;
     const uint32_t e = ++c->q_epoch;
-    Q.epoch = e;
-    Q.use_history = (keep_history && getf(c, "_RmTileFeedback", 1.0f) != 0.0f && c->q_last_mode == P.mode &&
-                     c->q_last_tiles == n_tiles && c->q_last_tx == tx && c->q_last_ty == ty) ? 1u : 0u;
+    Q.use_history = (keep_history && getf(c, "_RmTileFeedback", 1.0f) != 0.0f && same_shape) ? 1u : 0u;
     Q.cnt_cur = e & 1u; Q.cnt_clr = (e + 1u) & 1u;
     Q.hv_cur = e % 3u; Q.hv_nxt = (e + 1u) % 3u; Q.hv_clr = (e + 2u) % 3u;
-    Q.fl_cur = e & 1u; Q.fl_nxt = (e + 1u) & 1u;
-    if (!keep_history) { Q.flags = nullptr; }
     c->q_last_mode = keep_history ? P.mode : -1;
     c->q_last_tiles = n_tiles; c->q_last_tx = tx; c->q_last_ty = ty;
 
@@ -390,7 +399,7 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream) {
     unsigned blocks = want < resident ? want : resident;
     // static share: a fraction of the tiles, dealt evenly over the waves that will not start on a
     // heavy tile (at most heavy_cap of them do; the kernel uses the exact count)
-    float frac = getf(c, "_RmStaticFraction", 0.7f);
+    float frac = getf(c, "_RmStaticFraction", 0.5f);
     frac = frac < 0.0f ? 0.0f : (frac > 1.0f ? 1.0f : frac);
     Q.static_per_wave = (uint32_t)(frac * (float)n_tiles / (float)(blocks * 4));
     int rc = ensure_partials(c, blocks * 4, stream);

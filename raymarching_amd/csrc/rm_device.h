@@ -46,7 +46,7 @@ struct RmView {
 static_assert(sizeof(RmView) == 64, "RmView layout");
 
 // Tile queue of the persistent kernel and its frame-to-frame state (all device memory owned
-// by the context).  Three heavy-list sets and two counter/flag sets rotate so that a frame
+// by the context).  Three heavy-list/bitmap sets and two counter sets rotate so that a frame
 // never clears anything it, or a concurrently running wave of the same frame, still reads.
 #define RM_Q_SHARDS 8
 #ifndef RM_Q_CHUNK
@@ -60,16 +60,15 @@ struct RmQueue {
     uint32_t *counters;      // [2][RM_Q_SHARDS][RM_Q_STRIDE] claim counters (first word of each stride)
     uint32_t *heavy_count;   // [3]
     uint32_t *heavy_list;    // [3][heavy_cap] tile ids that were expensive in the previous frame
-    uint32_t *flags;         // [2][n_tiles] epoch in which a tile was put on a heavy list
+    uint32_t *bitmaps;       // [3][bitmap_words] one bit per tile: set = on the heavy list of that set
     uint32_t  n_tiles, tiles_x, tiles_y;
+    uint32_t  bitmap_words;  // ceil(n_tiles / 32), or 0 when no history is kept
     uint32_t  heavy_cap, heavy_threshold;
     uint32_t  scatter_mul;       // coprime with n_tiles
     uint32_t  static_per_wave;   // entries every wave without a heavy tile takes without claiming
-    uint32_t  epoch;         // this frame's number (monotonic per context)
     uint32_t  use_history;   // 0: previous frame unusable (first frame, size change)
     uint32_t  cnt_cur, cnt_clr;          // counter sets: in use / cleared for the next frame
     uint32_t  hv_cur, hv_nxt, hv_clr;    // heavy sets: read / appended / cleared
-    uint32_t  fl_cur, fl_nxt;            // flag sets: read / written
 };
 
 enum : int32_t { RM_MODE_FRAG = 0, RM_MODE_DEPTH_PERSP = 1, RM_MODE_DEPTH_ORTHO = 2 };
@@ -77,7 +76,7 @@ enum : int32_t { RM_MODE_FRAG = 0, RM_MODE_DEPTH_PERSP = 1, RM_MODE_DEPTH_ORTHO 
 struct RmParams {
     RmView   view;             // used when views == nullptr
     float    light[3];         // _WorldSpaceLightPos0.xyz
-    float    steps;            // min(2000, _MaxSteps)          (cginc:369, shader:104)
+    int32_t  n_steps;          // iterations of `for (i = 0; (float)i < min(2000,_MaxSteps); i++)` (cginc:369,372; shader:104,108)
     float    max_dist;         // _MaxDist
     float    shadow_depth;     // min(2000, _MaxDist)           (shader:103)
     float    far_plane;        // _ProjectionParams.z

@@ -36,34 +36,38 @@ namespace {
 
 struct MarchResult { bool hit; int evals; float length; float contact; };
 
-// cginc:367-392.  `steps` = min(2000,_MaxSteps), `depth` already min'ed with _MaxDist.
+// cginc:367-392.  `n_steps` = number of i >= 0 with (float)i < min(2000,_MaxSteps), `depth` already
+// min'ed with _MaxDist.  The loop only carries dm; whether it ended on the contact test is
+// re-derived from the last distance after the loop (same comparison, same operands).
 template <class S>
-RM_DI MarchResult rm_raymarch(const S &sc, V3 ro, V3 rd, float depth, float steps, float sf) {
+RM_DI MarchResult rm_raymarch(const S &sc, V3 ro, V3 rd, float depth, int n_steps, float sf) {
     const float kc = rm_vgpr(.0025f);
     MarchResult r;
-    r.hit = false; r.evals = 0; r.contact = 0.0f;
-    float dm = 0.0f;
-    for (int i = 0; (float)i < steps; i++) {
+    r.evals = 0;
+    float dm = 0.0f, adts = __builtin_inff(), contact = 0.0f;
+    for (int i = 0; i < n_steps; i++) {
         V3 cp = mk3(ro.x + rd.x * dm, ro.y + rd.y * dm, ro.z + rd.z * dm);
-        float dts = sc.w(cp);
+        adts = fabsf(sc.w(cp));
         r.evals++;
-        dm += fabsf(dts) * sf;
-        r.contact = dm * kc;
-        if (fabsf(dts) < r.contact) { r.hit = true; break; }
+        dm += adts * sf;
+        contact = dm * kc;
+        if (adts < contact) break;
         if (dm > depth) break;
     }
+    r.hit = adts < contact;
+    r.contact = contact;
     r.length = dm;
     return r;
 }
 
 // shader:102-123 with k = 16
 template <class S>
-RM_DI float rm_getshadow(const S &sc, V3 p, V3 n, V3 L, float contact, float depth, float steps, float sf, int &evals) {
+RM_DI float rm_getshadow(const S &sc, V3 p, V3 n, V3 L, float contact, float depth, int n_steps, float sf, int &evals) {
     const float kc = rm_vgpr(.0025f);
     float dm = 0.0f, res = 1.0f;
     p = mk3(p.x + (n.x * contact) * 2.0f, p.y + (n.y * contact) * 2.0f, p.z + (n.z * contact) * 2.0f);
     int ev = 0;
-    for (int i = 0; (float)i < steps; i++) {
+    for (int i = 0; i < n_steps; i++) {
         V3 cp = mk3(p.x + L.x * dm, p.y + L.y * dm, p.z + L.z * dm);
         float dts = sc.w(cp);
         ev++;
@@ -77,18 +81,22 @@ RM_DI float rm_getshadow(const S &sc, V3 p, V3 n, V3 L, float contact, float dep
     return res;
 }
 
+struct PixelOut { uint32_t rgba; float depth; uint32_t hit; size_t oidx; };
+
 // The whole fragment program for one pixel (x, local row yl, pose): primary march, and for a
 // hit pixel the six normal taps, the colour evaluation, the shadow march and the shade
 // (shader:149-216).  Miss pixels skip normal/shadow: the shader computes and then discards
-// them (shader:197-202).  Adds this pixel's counts to c_hit / c_p / c_s.
+// them (shader:197-202).  Adds this pixel's counts to c_hit / c_p / c_s.  Nothing is
+// stored here: the caller decides when the framebuffer writes are issued.
 template <class S>
-RM_DI void rm_shade_pixel(const RmParams &U, const S &sc, int x, int yl, int pose,
-                          unsigned &c_hit, unsigned &c_p, unsigned &c_s) {
+RM_DI PixelOut rm_compute_pixel(const RmParams &U, const S &sc, int x, int yl, int pose,
+                                unsigned &c_hit, unsigned &c_p, unsigned &c_s) {
+    PixelOut out;
     // compact local row -> frame row (row-band shard; identity when n_parts == 1)
     const int band = yl / U.band_rows;
     const int y = (band * U.n_parts + U.part) * U.band_rows + (yl - band * U.band_rows);
     const size_t gidx = (size_t)y * (size_t)U.w + (size_t)x;                    // full-frame index
-    const size_t oidx = ((size_t)pose * (size_t)U.rows + (size_t)yl) * (size_t)U.w + (size_t)x;
+    out.oidx = ((size_t)pose * (size_t)U.rows + (size_t)yl) * (size_t)U.w + (size_t)x;
 
     const RmView &V = U.views ? U.views[pose] : U.view;
     const float uu = ((float)x + 0.5f) / (float)U.w;
@@ -114,12 +122,14 @@ RM_DI void rm_shade_pixel(const RmParams &U, const S &sc, int x, int yl, int pos
     depth = fminf(depth, U.max_dist);                             // cginc:368
 
     const float sf = rm_vgpr(U.step_factor);
-    MarchResult r = rm_raymarch(sc, ro, rd, depth, U.steps, sf);
+    MarchResult r = rm_raymarch(sc, ro, rd, depth, U.n_steps, sf);
     c_p += (unsigned)r.evals;
     c_hit += r.hit ? 1u : 0u;
+    out.depth = r.length;
+    out.hit = r.hit ? 1u : 0u;
+    out.rgba = 0;
 
     if (U.mode == RM_MODE_FRAG) {
-        uint32_t rgba;
         if (r.hit) {
             const V3 L = mk3(rm_vgpr(U.light[0]), rm_vgpr(U.light[1]), rm_vgpr(U.light[2]));
             V3 hp = mk3(ro.x + rd.x * r.length, ro.y + rd.y * r.length, ro.z + rd.z * r.length);   // shader:174
@@ -130,7 +140,7 @@ RM_DI void rm_shade_pixel(const RmParams &U, const S &sc, int x, int yl, int pos
             V3 n = rm_normalize(raw);
             V4 s = sc.full(hp);                                                                   // shader:193
             int sev = 0;
-            float sh = rm_getshadow(sc, hp, n, L, r.contact, U.shadow_depth, U.steps, sf, sev);
+            float sh = rm_getshadow(sc, hp, n, L, r.contact, U.shadow_depth, U.n_steps, sf, sev);
             c_s += (unsigned)sev;
             float shadow = sh * 0.75f + .25f;                        // remap(x,0,1,.25,1), cginc:80-82
             float ndl = rm_dot3(n, L) * .5f + .5f;
@@ -138,16 +148,22 @@ RM_DI void rm_shade_pixel(const RmParams &U, const S &sc, int x, int yl, int pos
             float cr = ((s.x * ndl) * shadow) * ao;
             float cg = ((s.y * ndl) * shadow) * ao;
             float cb = ((s.z * ndl) * shadow) * ao;
-            rgba = rm_unorm8(cr) | (rm_unorm8(cg) << 8) | (rm_unorm8(cb) << 16) | 0xFF000000u;
+            out.rgba = rm_unorm8(cr) | (rm_unorm8(cg) << 8) | (rm_unorm8(cb) << 16) | 0xFF000000u;
         } else if (U.src) {
-            rgba = reinterpret_cast<const uint32_t *>(U.src)[gidx] | 0xFF000000u;
+            out.rgba = reinterpret_cast<const uint32_t *>(U.src)[gidx] | 0xFF000000u;
         } else {
-            rgba = U.bg_rgba8;
+            out.rgba = U.bg_rgba8;
         }
-        if (U.dst_rgba) reinterpret_cast<uint32_t *>(U.dst_rgba)[oidx] = rgba;
     }
-    if (U.dst_depth) U.dst_depth[oidx] = r.length;
-    if (U.dst_hit) U.dst_hit[oidx] = r.hit ? 1 : 0;
+    return out;
+}
+
+// one dword of colour, one of depth and one byte of mask per pixel; a wave writes an 8x8 tile
+// as eight 32-byte row segments per plane
+RM_DI void rm_store_pixel(const RmParams &U, const PixelOut &o) {
+    if (U.mode == RM_MODE_FRAG && U.dst_rgba) reinterpret_cast<uint32_t *>(U.dst_rgba)[o.oidx] = o.rgba;
+    if (U.dst_depth) U.dst_depth[o.oidx] = o.depth;
+    if (U.dst_hit) U.dst_hit[o.oidx] = (uint8_t)o.hit;
 }
 
 RM_DI unsigned rm_wave_sum(unsigned v) {
@@ -172,7 +188,7 @@ RM_DI void rm_pixel(const RmParams &U, const S &sc) {
     const int lane = tid & 63, wv = tid >> 6;
     const int x  = blockIdx.x * (8 * RM_BWX) + (wv % RM_BWX) * 8 + (lane & 7);
     const int yl = blockIdx.y * (8 * RM_BWY) + (wv / RM_BWX) * 8 + (lane >> 3);
-    if (x < U.w && yl < U.rows) rm_shade_pixel(U, sc, x, yl, (int)blockIdx.z, c_hit, c_p, c_s);
+    if (x < U.w && yl < U.rows) rm_store_pixel(U, rm_compute_pixel(U, sc, x, yl, (int)blockIdx.z, c_hit, c_p, c_s));
 
     // Counters: per-wave sums by cross-lane shuffles, per-block sums in LDS, then ONE plain
     // store per counter into this block's own slot.  No global atomics: same-address atomics
@@ -202,31 +218,41 @@ RM_DI void rm_pixel(const RmParams &U, const S &sc) {
 }
 
 // ---- kernel B: persistent waves pulling 8x8 tiles from an ordered queue --------------------
-// The grid is sized to what the chip holds at once; every wave loops: claim a queue entry,
-// render that tile, claim the next.  The queue lists the tiles that were expensive in the
-// previous frame of this context first (RmQueue::heavy_*), then all tiles in image order,
-// skipping the ones already listed.  A frame's critical path is its most expensive tile (a
-// few hundred dependent scene evaluations); starting those tiles at t = 0 hides them behind
-// the bulk of cheap tiles instead of leaving them as a tail.  Each tile is rendered exactly
-// once whatever the order, so the image does not depend on the history.
+// The grid is sized to what the chip holds at once; every wave loops: take a queue entry,
+// render that tile, take the next.  The queue lists the tiles that were expensive in the
+// previous frame of this context first, then all tiles in a scattered image order, skipping
+// the ones already listed.  A frame's critical path is its most expensive tile (a few hundred
+// dependent scene evaluations); starting those tiles at t = 0 on waves of their own hides them
+// behind the bulk of cheap tiles instead of leaving them as a tail.  Each tile is rendered
+// exactly once whatever the order, so the image does not depend on the history.
 //
-// Claims are atomic adds on RM_Q_SHARDS counters (entries interleaved over the shards, a wave
-// starts on shard = block index mod RM_Q_SHARDS and moves on when its shard runs dry); the
-// next claim is issued before the current tile is rendered so its latency is hidden.
+// Queue layout: [heavy tiles of the previous frame][static part][dynamic part].
+//  * wave w < n_heavy starts with heavy entry w, the others with their static share: every
+//    wave begins at t = 0 without touching a counter;
+//  * the static part (Q.static_per_wave entries per non-heavy wave, dealt cyclically) needs no
+//    atomics.  A device-scope returning atomic is a memory-side operation here (1-3 us, about
+//    90 per us and word): far too slow to claim every 3-us tile that way;
+//  * the dynamic part is claimed RM_Q_CHUNK entries at a time from RM_Q_SHARDS counters, each
+//    on its own 256-B line, by waves that have run out of static work; it evens out what the
+//    static deal left unbalanced.  The claiming atomic is issued BEFORE the current tile is
+//    rendered and its result is read after, ahead of the tile's framebuffer stores, so its
+//    latency hides behind the march and never queues behind the stores.
+//
+// "Was this tile on the heavy list?" is answered from a bitmap of the previous frame's list,
+// copied into LDS at kernel start (4 KB at 1080p).  Three bitmap/list sets rotate: read,
+// appended for the next frame, cleared for the one after.
 template <class S>
 RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
+    extern __shared__ unsigned s_bitmap[];
     const RmQueue &Q = U.queue;
     const int lane = threadIdx.x & 63;
-    const unsigned gw = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);   // global wave id, wave-uniform
+    const unsigned gw = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);   // global wave id
+    const unsigned n_waves = (gridDim.x * blockDim.x) >> 6;
     unsigned c_hit = 0, c_p = 0, c_s = 0;
 #ifdef RM_TIMELINE
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-    unsigned n_done = 0, max_cost = 0;
+    unsigned n_done = 0, max_cost = 0, t_wait = 0, n_claims = 0;
 #endif
-
-    // frame-to-frame state: this frame reads set `cur`, appends to `nxt`, clears `clr`
-    if (gw == 0 && lane < RM_Q_SHARDS) Q.counters[(Q.cnt_clr * RM_Q_SHARDS + lane) * RM_Q_STRIDE] = 0u;
-    if (gw == 0 && lane == 0) Q.heavy_count[Q.hv_clr] = 0u;
 
     unsigned n_heavy = 0;
     if (Q.use_history) {
@@ -237,95 +263,124 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
     const unsigned n_entries = n_heavy + Q.n_tiles;
     const unsigned *heavy_cur = Q.heavy_list + (size_t)Q.hv_cur * Q.heavy_cap;
     unsigned *heavy_nxt = Q.heavy_list + (size_t)Q.hv_nxt * Q.heavy_cap;
-    const unsigned *flag_cur = Q.flags + (size_t)Q.fl_cur * Q.n_tiles;
-    unsigned *flag_nxt = Q.flags + (size_t)Q.fl_nxt * Q.n_tiles;
+    unsigned *bitmap_nxt = Q.bitmaps + (size_t)Q.hv_nxt * Q.bitmap_words;
     unsigned *counters = Q.counters + Q.cnt_cur * RM_Q_SHARDS * RM_Q_STRIDE;
 
-    // Queue layout: [heavy tiles of the previous frame][static part][dynamic part].
-    //  * wave w < n_heavy starts with heavy entry w, the other waves with their static share:
-    //    every wave begins at t = 0 without touching a counter, and each expensive tile gets
-    //    a wave of its own;
-    //  * the static part (Q.static_per_wave entries per non-heavy wave, dealt cyclically) covers
-    //    most of the frame without atomics: a device-scope returning atomic is a memory-side
-    //    operation here (~1-3 us, ~90 per us and word), far too slow to claim every 3-us tile;
-    //  * the dynamic part is claimed RM_Q_CHUNK entries at a time from RM_Q_SHARDS counters, each on
-    //    its own 256-B line, by waves that have run out of static work -- it evens out what
-    //    the static deal left unbalanced.  The claim for the next entry is issued before the
-    //    current tile is rendered.
-    const unsigned n_waves = (gridDim.x * blockDim.x) >> 6;
+    // frame-to-frame housekeeping: clear what the NEXT frame will append to / claim from
+    if (gw == 0 && lane < RM_Q_SHARDS) Q.counters[(Q.cnt_clr * RM_Q_SHARDS + lane) * RM_Q_STRIDE] = 0u;
+    if (gw == 0 && lane == 0) Q.heavy_count[Q.hv_clr] = 0u;
+    {
+        unsigned *bitmap_clr = Q.bitmaps + (size_t)Q.hv_clr * Q.bitmap_words;
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < Q.bitmap_words; i += gridDim.x * blockDim.x) bitmap_clr[i] = 0u;
+    }
+    // this frame's heavy bitmap -> LDS
+    if (Q.use_history) {
+        const unsigned *bitmap_cur = Q.bitmaps + (size_t)Q.hv_cur * Q.bitmap_words;
+        for (unsigned i = threadIdx.x; i < Q.bitmap_words; i += blockDim.x) s_bitmap[i] = bitmap_cur[i];
+    }
+    __syncthreads();
+
     const unsigned n_static_waves = n_waves > n_heavy ? n_waves - n_heavy : 0u;
     const unsigned static_end = n_heavy + Q.static_per_wave * n_static_waves;      // <= n_entries by construction
-    unsigned shard = blockIdx.x % RM_Q_SHARDS, tried = 0;
+    unsigned shard = blockIdx.x % RM_Q_SHARDS, dry = 0;      // dry: bit s set = shard s is exhausted
     unsigned static_left = gw >= n_heavy ? Q.static_per_wave : 0u;
     unsigned static_next = n_heavy + (gw - n_heavy);
     unsigned dyn_left = 0, dyn_next = 0;
-    auto claim = [&]() -> unsigned {
-        // returns an entry index, or 0xffffffff when the queue is exhausted
-        if (static_left) {
-            unsigned e = static_next;
-            static_next += n_static_waves;
-            static_left--;
-            return e;
-        }
-        if (dyn_left) { dyn_left--; return dyn_next++; }
-        unsigned e = 0xffffffffu;
-        while (tried < RM_Q_SHARDS) {
-            // a dry shard is recognised by a plain load before spending an atomic on it
-            unsigned k = __hip_atomic_load(&counters[shard * RM_Q_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            k = __builtin_amdgcn_readfirstlane(k);
-            if (static_end + (k * RM_Q_SHARDS + shard) * RM_Q_CHUNK < n_entries) {
-                if (lane == 0) k = atomicAdd(&counters[shard * RM_Q_STRIDE], 1u);
-                k = __builtin_amdgcn_readfirstlane(k);
-                unsigned first = static_end + (k * RM_Q_SHARDS + shard) * RM_Q_CHUNK;
-                if (first < n_entries) {
-                    unsigned last = first + RM_Q_CHUNK < n_entries ? first + RM_Q_CHUNK : n_entries;
-                    e = first; dyn_next = first + 1; dyn_left = last - first - 1;
-                    break;
-                }
-            }
-            shard = (shard + 1) % RM_Q_SHARDS;
-            tried++;
-        }
-        return e;
-    };
 
-    unsigned nxt = gw < n_heavy ? gw : claim();
-    while (nxt != 0xffffffffu) {
-        const unsigned cur = nxt;
-        nxt = claim();
-        unsigned tile;
-        // A tile from the heavy list is a long dependent chain that the frame cannot end before:
-        // its wave gets issue priority over the waves that render cheap tiles on the same SIMD.
-        if (cur < n_heavy) __builtin_amdgcn_s_setprio(RM_HEAVY_PRIO); else __builtin_amdgcn_s_setprio(0);
-        if (cur < n_heavy) {
-            tile = heavy_cur[cur];
-        } else {
-            // image-order position -> tile through a fixed bijection (multiplication by a number
-            // coprime with n_tiles): the tiles one wave gets from its cyclic static share are
-            // scattered over the image instead of lining up in one image column
-            tile = (unsigned)(((unsigned long long)(cur - n_heavy) * Q.scatter_mul) % Q.n_tiles);
-            if (Q.use_history && flag_cur[tile] == Q.epoch) continue;       // rendered through the heavy list
-        }
-        tile = __builtin_amdgcn_readfirstlane(tile);
-        const unsigned per_pose = Q.tiles_x * Q.tiles_y;
-        const unsigned pose = tile / per_pose, t2 = tile - pose * per_pose;
-        const unsigned ty = t2 / Q.tiles_x, tx = t2 - ty * Q.tiles_x;
-        const int x = (int)(tx * 8u) + (lane & 7), yl = (int)(ty * 8u) + (lane >> 3);
-        unsigned t_hit = 0, t_p = 0, t_s = 0;
-        if (x < U.w && yl < U.rows) rm_shade_pixel(U, sc, x, yl, (int)pose, t_hit, t_p, t_s);
-        c_hit += t_hit; c_p += t_p; c_s += t_s;
-        // cost of this tile for the wave = its longest pixel; remember expensive tiles for the next frame
-        unsigned cost = t_p + t_s + (t_hit ? 7u : 0u);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { unsigned v = __shfl_xor(cost, o); cost = cost > v ? cost : v; }
-#ifdef RM_TIMELINE
-        n_done++; max_cost = max_cost > cost ? max_cost : cost;
-#endif
-        if (cost >= Q.heavy_threshold && lane == 0) {
-            unsigned idx = atomicAdd(&Q.heavy_count[Q.hv_nxt], 1u);
-            if (idx < Q.heavy_cap) { heavy_nxt[idx] = tile; flag_nxt[tile] = Q.epoch + 1u; }
-        }
+    // entry -> tile id, or 0xffffffff for an entry that must be skipped
+    auto entry_tile = [&](unsigned e) -> unsigned {
+        if (e < n_heavy) return __builtin_amdgcn_readfirstlane(heavy_cur[e]);
+        // image-order position -> tile through a fixed bijection (multiplication by a number
+        // coprime with n_tiles): the tiles a wave gets from its cyclic static share are
+        // scattered over the image instead of lining up in one image column
+        unsigned t = (unsigned)(((unsigned long long)(e - n_heavy) * Q.scatter_mul) % Q.n_tiles);
+        if (Q.use_history && ((s_bitmap[t >> 5] >> (t & 31)) & 1u)) return 0xffffffffu;   // rendered through the heavy list
+        return t;
+    };
+    // next entry without an atomic, or 0xffffffff if the wave has to claim
+    auto local_next = [&]() -> unsigned {
+        if (static_left) { unsigned e = static_next; static_next += n_static_waves; static_left--; return e; }
+        if (dyn_left) { dyn_left--; return dyn_next++; }
+        return 0xffffffffu;
+    };
+    auto chunk_first = [&](unsigned k, unsigned s) -> unsigned { return static_end + (k * RM_Q_SHARDS + s) * RM_Q_CHUNK; };
+
+    bool done = false;
+    unsigned cur = gw < n_heavy ? gw : local_next();
+    if (cur == 0xffffffffu) {
+        // no static share (tiny frame): first claim, synchronously
+        unsigned k = 0;
+        if (lane == 0) k = atomicAdd(&counters[shard * RM_Q_STRIDE], 1u);
+        k = __builtin_amdgcn_readfirstlane(k);
+        cur = chunk_first(k, shard);
+        if (cur >= n_entries) { cur = 0xffffffffu; dry |= 1u << shard; }
+        else { unsigned last = cur + RM_Q_CHUNK < n_entries ? cur + RM_Q_CHUNK : n_entries; dyn_next = cur + 1; dyn_left = last - cur - 1; }
     }
+    while (!done) {
+        // 1. the entry after `cur`: from the wave's own stock, or by an atomic issued now and read in step 3
+        unsigned nxt = local_next();
+        bool claiming = false;
+        unsigned k_raw = 0;
+        if (nxt == 0xffffffffu && dry != (1u << RM_Q_SHARDS) - 1u) {
+            while (dry & (1u << shard)) shard = (shard + 1) % RM_Q_SHARDS;
+            if (lane == 0) k_raw = atomicAdd(&counters[shard * RM_Q_STRIDE], 1u);
+            claiming = true;
+        }
+        // 2. render `cur` (registers only)
+        PixelOut po;
+        bool have = false;
+        unsigned tile = cur == 0xffffffffu ? 0xffffffffu : entry_tile(cur);
+        unsigned t_hit = 0, t_p = 0, t_s = 0;
+        if (tile != 0xffffffffu) {
+            // a tile from the heavy list is a long dependent chain that the frame cannot end before:
+            // its wave gets issue priority over waves rendering cheap tiles on the same SIMD
+            if (cur < n_heavy) __builtin_amdgcn_s_setprio(RM_HEAVY_PRIO); else __builtin_amdgcn_s_setprio(0);
+            const unsigned per_pose = Q.tiles_x * Q.tiles_y;
+            const unsigned pose = tile / per_pose, t2 = tile - pose * per_pose;
+            const unsigned ty = t2 / Q.tiles_x, tx = t2 - ty * Q.tiles_x;
+            const int x = (int)(tx * 8u) + (lane & 7), yl = (int)(ty * 8u) + (lane >> 3);
+            if (x < U.w && yl < U.rows) { po = rm_compute_pixel(U, sc, x, yl, (int)pose, t_hit, t_p, t_s); have = true; }
+            c_hit += t_hit; c_p += t_p; c_s += t_s;
+        }
+        // 3. the claim has had the whole tile to come back; read it before the stores go out
+        if (claiming) {
+#ifdef RM_TIMELINE
+            const unsigned long long tw0 = __builtin_amdgcn_s_memrealtime();
+#endif
+            unsigned k = __builtin_amdgcn_readfirstlane(k_raw);
+#ifdef RM_TIMELINE
+            asm volatile("" :: "s"(k));
+            t_wait += (unsigned)(__builtin_amdgcn_s_memrealtime() - tw0); n_claims++;
+#endif
+            unsigned first = chunk_first(k, shard);
+            if (first < n_entries) {
+                unsigned last = first + RM_Q_CHUNK < n_entries ? first + RM_Q_CHUNK : n_entries;
+                nxt = first; dyn_next = first + 1; dyn_left = last - first - 1;
+            } else {
+                dry |= 1u << shard;                       // try the next shard on the next round
+                nxt = 0xffffffffu;
+                if (dry == (1u << RM_Q_SHARDS) - 1u) done = true;
+            }
+        } else if (nxt == 0xffffffffu) {
+            done = true;
+        }
+        // 4. framebuffer stores of `cur`, and its cost for the next frame's ordering
+        if (tile != 0xffffffffu) {
+            if (have) rm_store_pixel(U, po);
+            unsigned cost = t_p + t_s + (t_hit ? 7u : 0u);    // this lane's scene evaluations; wave max = the tile's length
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { unsigned v = __shfl_xor(cost, o); cost = cost > v ? cost : v; }
+#ifdef RM_TIMELINE
+            n_done++; max_cost = max_cost > cost ? max_cost : cost;
+#endif
+            if (cost >= Q.heavy_threshold && lane == 0) {
+                unsigned idx = atomicAdd(&Q.heavy_count[Q.hv_nxt], 1u);
+                if (idx < Q.heavy_cap) { heavy_nxt[idx] = tile; atomicOr(&bitmap_nxt[tile >> 5], 1u << (tile & 31)); }
+            }
+        }
+        cur = nxt;
+    }
+    __builtin_amdgcn_s_setprio(0);
 
     c_hit = rm_wave_sum(c_hit); c_p = rm_wave_sum(c_p); c_s = rm_wave_sum(c_s);
     if (lane == 0) {
@@ -335,6 +390,7 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
         const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
         o[3] = (unsigned)t_start; o[4] = (unsigned)(t_start >> 32); o[5] = (unsigned)t_end; o[6] = (unsigned)(t_end >> 32);
         o[7] = n_done | (max_cost << 16);
+        o[0] = t_wait; o[1] = n_claims;       // timeline builds repurpose the counters
 #endif
     }
 }
@@ -370,14 +426,25 @@ __global__ RM_LB void rm_tile_kernelN(const RmParams U) {
     rm_pixel(U, sc);
 }
 
+// 4 waves per SIMD (<= 128 VGPRs): measured best for the persistent kernel (3 starves the VALU,
+// 5+ slows the waves that carry a frame's longest tiles)
+#ifndef RM_Q_MIN_WAVES
+#define RM_Q_MIN_WAVES 4
+#endif
+#ifdef RM_Q_MIN_WAVES
+#define RM_QLB __launch_bounds__(256, RM_Q_MIN_WAVES)
+#else
+#define RM_QLB __launch_bounds__(256)
+#endif
+
 template <bool ROT, int SCL>
-__global__ __launch_bounds__(256) void rm_queue_kernel4(const RmParams U) {
+__global__ RM_QLB void rm_queue_kernel4(const RmParams U) {
     Scene4<ROT, SCL> sc(U);
     rm_queue_body(U, sc);
 }
 
 template <bool ROT, int SCL>
-__global__ __launch_bounds__(256) void rm_queue_kernelN(const RmParams U) {
+__global__ RM_QLB void rm_queue_kernelN(const RmParams U) {
     SceneN<ROT, SCL> sc(U.prim_table, U.n_prims);
     rm_queue_body(U, sc);
 }
@@ -386,15 +453,16 @@ template <bool ROT, int SCL>
 hipError_t launch_queue_variant(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu) {
     if (blocks_per_cu) {
         int n4 = 0, nN = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, rm_queue_kernel4<ROT, SCL>, 256, 0);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, rm_queue_kernel4<ROT, SCL>, 256, (size_t)U.queue.bitmap_words * 4);
         if (e != hipSuccess) return e;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nN, rm_queue_kernelN<ROT, SCL>, 256, 0);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nN, rm_queue_kernelN<ROT, SCL>, 256, (size_t)U.queue.bitmap_words * 4);
         if (e != hipSuccess) return e;
         blocks_per_cu[0] = n4; blocks_per_cu[1] = nN;
         return hipSuccess;
     }
-    if (U.n_prims > 0) hipLaunchKernelGGL((rm_queue_kernelN<ROT, SCL>), dim3(blocks), dim3(256), 0, stream, U);
-    else               hipLaunchKernelGGL((rm_queue_kernel4<ROT, SCL>), dim3(blocks), dim3(256), 0, stream, U);
+    const size_t lds = (size_t)U.queue.bitmap_words * 4;
+    if (U.n_prims > 0) hipLaunchKernelGGL((rm_queue_kernelN<ROT, SCL>), dim3(blocks), dim3(256), lds, stream, U);
+    else               hipLaunchKernelGGL((rm_queue_kernel4<ROT, SCL>), dim3(blocks), dim3(256), lds, stream, U);
     return hipGetLastError();
 }
 

@@ -91,9 +91,12 @@ template <class PT> RM_DI float rm_torus(const PT &P, V3 p) {
 
 // distance lane of smin(float4 a, float4 b, .5)  (cginc:110-113)
 RM_DI float rm_smin_h(float a, float b) { return rm_clamp01(0.5f + (b - a)); }
+// lerp(b,a,h) = b + h*(a-b) is evaluated as b - h*(b-a): a-b == -(b-a) and h*(-e) == -(h*e)
+// hold exactly in binary floating point, so one subtraction serves both h and the lerp
 RM_DI float rm_smin_w(float a, float b) {
-    float h = rm_smin_h(a, b);
-    return rm_lerp(b, a, h) - (0.5f * h) * (1.0f - h);
+    float e = b - a;
+    float h = rm_clamp01(0.5f + e);
+    return (b - h * e) - (0.5f * h) * (1.0f - h);
 }
 // full smin: rgb through blend() (cginc:101-103)
 RM_DI V4 rm_smin4(V4 a, V4 b) {

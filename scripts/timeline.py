@@ -32,6 +32,7 @@ print("per-slot tiles done: mean %.1f max %d; max tile cost seen %d" % ((s[:,7]&
 print("wave end-time percentiles 10/50/90/99/100:", np.round(np.percentile(en,[10,50,90,99,100]),1))
 hv=(s[:,7]>>16)>=40
 print("waves that saw a heavy tile:", int(hv.sum()), "their end times p50/max: %.1f %.1f" % (np.median(en[hv]), en[hv].max()), "; others p50/max: %.1f %.1f" % (np.median(en[~hv]), en[~hv].max()))
+if os.environ.get("RM_KERNEL")=="2": print("claims per wave mean %.1f; wait per claim mean %.2f us; wait per wave mean %.1f us max %.1f us" % (s[:,1].mean(), s[:,0].sum()/max(1,s[:,1].sum())/100.0, s[:,0].mean()/100.0, s[:,0].max()/100.0))
 edges = np.arange(0, en.max() + 5, 5.0)
 resident = [(int(((st <= t) & (en > t)).sum())) for t in edges]
 print("resident blocks every 5 us:", resident)

@@ -20,7 +20,7 @@ __global__ void check(uint32_t first, unsigned long long *bad, uint32_t *example
     float x = __uint_as_float(bits);
     float ref = (float)sqrt((double)x);
     float ref2 = sqrtf(x);
-    if (__float_as_uint(ref) != __float_as_uint(ref2)) atomicAdd(bad + 4, 1ull);
+    if (__float_as_uint(ref) != __float_as_uint(ref2)) atomicAdd(bad + 5, 1ull);
     float got = cand_a(x);
     if (__float_as_uint(ref) != __float_as_uint(got)) {
         atomicAdd(bad, 1ull);
@@ -32,14 +32,14 @@ __global__ void raw_ulp(uint32_t first, unsigned long long *cnt) {   // how ofte
     uint32_t bits = first + blockIdx.x * blockDim.x + threadIdx.x;
     float x = __uint_as_float(bits);
     int d = (int)__float_as_uint(__builtin_amdgcn_sqrtf(x)) - (int)__float_as_uint((float)sqrt((double)x));
-    if (d == 0) atomicAdd(&cnt[0], 1ull); else if (d == 1 || d == -1) atomicAdd(&cnt[1], 1ull); else atomicAdd(&cnt[2], 1ull);
+    if (d == 0) atomicAdd(&cnt[0], 1ull); else if (d == 1) atomicAdd(&cnt[1], 1ull); else if (d == -1) atomicAdd(&cnt[3], 1ull); else atomicAdd(&cnt[2], 1ull);
 }
 
 int main() {
-    unsigned long long *bad, h[5] = {0, 0, 0, 0, 0};
+    unsigned long long *bad, h[6] = {0, 0, 0, 0, 0, 0};
     uint32_t *ex, hex = 0;
-    hipMalloc(&bad, 40); hipMalloc(&ex, 4);
-    hipMemset(bad, 0, 40); hipMemset(ex, 0, 4);
+    hipMalloc(&bad, 48); hipMalloc(&ex, 4);
+    hipMemset(bad, 0, 48); hipMemset(ex, 0, 4);
     // exponents 127-96 .. 127+96 -> bits [ (31<<23), (224<<23) )
     uint32_t lo = 31u << 23, hi = 224u << 23;
     unsigned long long total = 0;
@@ -51,10 +51,10 @@ int main() {
     }
     hipLaunchKernelGGL(check, dim3(1), dim3(256), 0, 0, 0u, bad, ex);      // 0 and the smallest denormals
     hipDeviceSynchronize();
-    hipMemcpy(h, bad, 40, hipMemcpyDeviceToHost);
+    hipMemcpy(h, bad, 48, hipMemcpyDeviceToHost);
     hipMemcpy(&hex, ex, 4, hipMemcpyDeviceToHost);
     printf("checked %llu values: candidate mismatches %llu (example bits 0x%08x)\n", total, h[0], hex);
-    printf("sqrtf() vs (float)sqrt(double): %llu mismatches\n", h[4]);
-    printf("raw v_sqrt_f32: exact %llu, off by 1 ulp %llu, worse %llu\n", h[1], h[2], h[3]);
+    printf("sqrtf() vs (float)sqrt(double): %llu mismatches\n", h[5]);
+    printf("raw v_sqrt_f32: exact %llu, +1 ulp (too big) %llu, -1 ulp (too small) %llu, worse %llu\n", h[1], h[2], h[4], h[3]);
     return h[0] != 0;
 }
