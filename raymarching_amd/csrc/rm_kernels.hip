@@ -134,9 +134,15 @@ RM_DI PixelOut rm_compute_pixel(const RmParams &U, const S &sc, int x, int yl, i
             const V3 L = mk3(rm_vgpr(U.light[0]), rm_vgpr(U.light[1]), rm_vgpr(U.light[2]));
             V3 hp = mk3(ro.x + rd.x * r.length, ro.y + rd.y * r.length, ro.z + rd.z * r.length);   // shader:174
             const float e = U.nss;
-            V3 raw = mk3(sc.w(mk3(hp.x + e, hp.y, hp.z)) - sc.w(mk3(hp.x - e, hp.y, hp.z)),        // shader:63-67
-                         sc.w(mk3(hp.x, hp.y + e, hp.z)) - sc.w(mk3(hp.x, hp.y - e, hp.z)),
-                         sc.w(mk3(hp.x, hp.y, hp.z + e)) - sc.w(mk3(hp.x, hp.y, hp.z - e)));
+            // shader:63-67: central differences along x, y, z.  Kept as a rolled loop: unrolled, the
+            // scheduler interleaves all six evaluations and the register file overflows into scratch.
+            V3 raw = mk3(0.0f, 0.0f, 0.0f);
+#pragma nounroll
+            for (int a = 0; a < 3; a++) {
+                const V3 o = mk3(a == 0 ? e : 0.0f, a == 1 ? e : 0.0f, a == 2 ? e : 0.0f);
+                const float d = sc.w(mk3(hp.x + o.x, hp.y + o.y, hp.z + o.z)) - sc.w(mk3(hp.x - o.x, hp.y - o.y, hp.z - o.z));
+                raw.x = a == 0 ? d : raw.x; raw.y = a == 1 ? d : raw.y; raw.z = a == 2 ? d : raw.z;
+            }
             V3 n = rm_normalize(raw);
             V4 s = sc.full(hp);                                                                   // shader:193
             int sev = 0;
@@ -426,16 +432,17 @@ __global__ RM_LB void rm_tile_kernelN(const RmParams U) {
     rm_pixel(U, sc);
 }
 
-// 4 waves per SIMD (<= 128 VGPRs): measured best for the persistent kernel (3 starves the VALU,
-// 5+ slows the waves that carry a frame's longest tiles)
+// Waves per SIMD the register allocator is asked to fit.  4 (<= 128 VGPRs) is the measured best
+// for the persistent kernel on the unrotated scene (3 starves the VALU, 5+ slows the waves that
+// carry a frame's longest tiles); the variants with per-primitive rotation keep 20 more constants
+// per primitive in registers and would spill at 128, so they run 3 waves (<= 168 VGPRs).
 #ifndef RM_Q_MIN_WAVES
 #define RM_Q_MIN_WAVES 4
 #endif
-#ifdef RM_Q_MIN_WAVES
-#define RM_QLB __launch_bounds__(256, RM_Q_MIN_WAVES)
-#else
-#define RM_QLB __launch_bounds__(256)
+#ifndef RM_Q_MIN_WAVES_ROT
+#define RM_Q_MIN_WAVES_ROT 3
 #endif
+#define RM_QLB __launch_bounds__(256, (ROT ? RM_Q_MIN_WAVES_ROT : RM_Q_MIN_WAVES))
 
 template <bool ROT, int SCL>
 __global__ RM_QLB void rm_queue_kernel4(const RmParams U) {
