@@ -1,0 +1,102 @@
+// RmHip.cs -- P/Invoke surface of librmhip.so (include/rmhip.h), one entry per C symbol.
+// Drop this file and librmhip.so (Assets/Plugins/x86_64) into the Unity project.
+using System;
+using System.Runtime.InteropServices;
+
+public static class RmHip
+{
+    const string Lib = "rmhip";
+
+    public const int RM_OK = 0, RM_E_ARG = -1, RM_E_DEVICE = -2, RM_E_NOMEM = -3, RM_E_RANGE = -4;
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct Primitive
+    {
+        public int type, op;
+        public float px, py, pz;
+        public float qx, qy, qz, qw;
+        public float sx, sy, sz;
+        public float r, g, b;
+        public float p0, p1, p2, p3;
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct Stats { public ulong nPixels, nHit, sumStepsPrimary, sumStepsShadow; }
+
+    [DllImport(Lib)] public static extern IntPtr rm_create(int hipDevice);
+    [DllImport(Lib)] public static extern void rm_destroy(IntPtr ctx);
+    [DllImport(Lib)] public static extern IntPtr rm_last_error(IntPtr ctx);
+    [DllImport(Lib)] public static extern IntPtr rm_version();
+
+    [DllImport(Lib)] public static extern int rm_set_float(IntPtr ctx, string name, float value);
+    [DllImport(Lib)] public static extern int rm_set_int(IntPtr ctx, string name, int value);
+    [DllImport(Lib)] public static extern int rm_set_vector(IntPtr ctx, string name, float[] v4);
+    [DllImport(Lib)] public static extern int rm_set_matrix(IntPtr ctx, string name, float[] m16);
+    [DllImport(Lib)] public static extern int rm_get_float(IntPtr ctx, string name, out float value);
+    [DllImport(Lib)] public static extern int rm_get_int(IntPtr ctx, string name, out int value);
+    [DllImport(Lib)] public static extern int rm_get_vector(IntPtr ctx, string name, [Out] float[] v4);
+    [DllImport(Lib)] public static extern int rm_get_matrix(IntPtr ctx, string name, [Out] float[] m16);
+    [DllImport(Lib)] public static extern int rm_has_property(IntPtr ctx, string name);
+    [DllImport(Lib)] public static extern int rm_set_primitives(IntPtr ctx, Primitive[] prims, int n);
+
+    [DllImport(Lib)] public static extern int rm_blit(IntPtr ctx, IntPtr srcRgba8, IntPtr sceneDepth,
+                                                      IntPtr dstRgba8, IntPtr dstDepth, IntPtr dstHit, int w, int h);
+    [DllImport(Lib)] public static extern int rm_blit_device(IntPtr ctx, IntPtr dSrc, IntPtr dSceneDepth,
+                                                             IntPtr dRgba8, IntPtr dDepth, IntPtr dHit, int w, int h, IntPtr hipStream);
+    [DllImport(Lib)] public static extern int rm_band_rows(int h, int bandRows, int part, int nParts);
+    [DllImport(Lib)] public static extern int rm_blit_bands_device(IntPtr ctx, IntPtr dSrc, IntPtr dSceneDepth, IntPtr dRgba8, IntPtr dDepth,
+                                                                   IntPtr dHit, int w, int h, int bandRows, int part, int nParts, IntPtr hipStream);
+    [DllImport(Lib)] public static extern int rm_blit_poses_device(IntPtr ctx, int nPoses, float[] frustumCorners, float[] camInvView, float[] camPos,
+                                                                   IntPtr dRgba8, IntPtr dDepth, IntPtr dHit, int w, int h, IntPtr hipStream);
+    [DllImport(Lib)] public static extern int rm_shadowmap_render(IntPtr ctx, IntPtr dstDepth, int w, int h);
+    [DllImport(Lib)] public static extern int rm_shadowmap_render_device(IntPtr ctx, IntPtr dDepth, IntPtr dHit, int w, int h, IntPtr hipStream);
+    [DllImport(Lib)] public static extern int rm_shadowmap_directional(IntPtr ctx, float[] corners12, float[] forward3, IntPtr dstDepth, int w, int h);
+    [DllImport(Lib)] public static extern int rm_shadowmap_directional_device(IntPtr ctx, float[] corners12, float[] forward3, IntPtr dDepth, IntPtr dHit,
+                                                                              int w, int h, IntPtr hipStream);
+    [DllImport(Lib)] public static extern int rm_get_stats(IntPtr ctx, out Stats stats);
+    [DllImport(Lib)] public static extern int rm_debug_counter_slots(IntPtr ctx, [Out] uint[] words, int maxWords, out int wordsPerSlot, out int nSlots);
+    [DllImport(Lib)] public static extern int rm_set_kernel(IntPtr ctx, int variant);
+
+    public static string LastError(IntPtr ctx) { return Marshal.PtrToStringAnsi(rm_last_error(ctx)); }
+
+    public static void Check(IntPtr ctx, int rc)
+    {
+        if (rc != RM_OK) throw new InvalidOperationException("librmhip " + rc + ": " + LastError(ctx));
+    }
+
+    // UnityEngine.Matrix4x4 is sixteen floats in column-major field order: it can be passed as is.
+    public static float[] Floats(UnityEngine.Matrix4x4 m)
+    {
+        return new[] { m.m00, m.m10, m.m20, m.m30, m.m01, m.m11, m.m21, m.m31, m.m02, m.m12, m.m22, m.m32, m.m03, m.m13, m.m23, m.m33 };
+    }
+}
+
+// The property-bag half of UnityEngine.Material, backed by an rm_ctx.
+public sealed class RmMaterial : IDisposable
+{
+    public IntPtr Ctx { get; private set; }
+
+    public RmMaterial(int hipDevice = 0)
+    {
+        Ctx = RmHip.rm_create(hipDevice);
+        if (Ctx == IntPtr.Zero) throw new InvalidOperationException("rm_create: " + RmHip.LastError(IntPtr.Zero));
+    }
+
+    public void SetFloat(string name, float v) { RmHip.Check(Ctx, RmHip.rm_set_float(Ctx, name, v)); }
+    public void SetInt(string name, int v) { RmHip.Check(Ctx, RmHip.rm_set_int(Ctx, name, v)); }
+    public void SetVector(string name, UnityEngine.Vector4 v) { RmHip.Check(Ctx, RmHip.rm_set_vector(Ctx, name, new[] { v.x, v.y, v.z, v.w })); }
+    public void SetMatrix(string name, UnityEngine.Matrix4x4 m) { RmHip.Check(Ctx, RmHip.rm_set_matrix(Ctx, name, RmHip.Floats(m))); }
+    public float GetFloat(string name) { float v; RmHip.Check(Ctx, RmHip.rm_get_float(Ctx, name, out v)); return v; }
+    public bool HasProperty(string name) { return RmHip.rm_has_property(Ctx, name) != 0; }
+
+    // copies the floats the inspector serialized on the Unity material into the plugin
+    public void CopyFloatsFrom(UnityEngine.Material mat, params string[] names)
+    {
+        foreach (var n in names) if (mat.HasProperty(n)) SetFloat(n, mat.GetFloat(n));
+    }
+
+    public void Dispose()
+    {
+        if (Ctx != IntPtr.Zero) { RmHip.rm_destroy(Ctx); Ctx = IntPtr.Zero; }
+    }
+}

@@ -117,3 +117,17 @@ def test_package_never_touches_the_oracle():
             if fn.endswith((".py", ".cpp", ".hip", ".h", ".hpp", ".cs")) or fn == "Makefile":
                 txt = open(os.path.join(dirpath, fn), errors="ignore").read()
                 assert "oracle" not in txt.lower(), f"{fn} mentions the oracle"
+
+
+def test_cpp_host_mirror_builds_and_runs(tmp_path):
+    """include/rmhip.hpp (C++ mirror of Material / Graphics.Blit / the three scripts) against the library"""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "cpp_host_mirror")
+    libdir = os.path.join(ROOT, "raymarching_amd")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "cpp_host_mirror.cpp"),
+                    "-L" + libdir, "-lrmhip", "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert out.strip().endswith("ok")
