@@ -164,11 +164,13 @@ mat4 getm(rm_ctx *c, const char *n) {
     return it == c->matrices.end() ? mat_identity() : it->second;
 }
 
-bool is_pow2(float s) {
-    if (!(s > 0.0f) || !std::isfinite(s)) return false;
-    int e;
-    float m = std::frexp(s, &e);
-    return m == 0.5f && e > -100 && e < 100;
+// may p/s be computed from RN(1/s) with one residual correction (rm_div_by in rm_math.h)?
+bool rcp_safe(float s) {
+    if (!std::isfinite(s) || s == 0.0f) return false;
+    uint32_t b;
+    std::memcpy(&b, &s, 4);
+    int e = (int)((b >> 23) & 0xff) - 127;
+    return e >= -60 && e <= 60 && (b & 0x7fffffu) != 0x7fffffu;
 }
 
 uint32_t unorm8(float x) {
@@ -196,7 +198,10 @@ RmPrimDev prepare_prim(const rm_primitive &p) {
     int flags = 0;
     if (p.quat[0] == 0.0f && p.quat[1] == 0.0f && p.quat[2] == 0.0f && p.quat[3] == 1.0f) flags |= RM_PF_IDENT_ROT;
     if (p.scale[0] == 1.0f && p.scale[1] == 1.0f && p.scale[2] == 1.0f) flags |= RM_PF_UNIT_SCALE;
-    if (is_pow2(p.scale[0]) && is_pow2(p.scale[1]) && is_pow2(p.scale[2])) flags |= RM_PF_RCP;
+    if (rcp_safe(p.scale[0]) && rcp_safe(p.scale[1]) && rcp_safe(p.scale[2])) {
+        flags |= RM_PF_RCP;
+        d.rx = 1.0f / p.scale[0]; d.ry = 1.0f / p.scale[1]; d.rz = 1.0f / p.scale[2];
+    }
     d.flags = flags;
     d.sx = p.scale[0]; d.sy = p.scale[1]; d.sz = p.scale[2];
     return d;
@@ -292,18 +297,11 @@ int build_params(rm_ctx *c, RmParams *U, hipStream_t stream) {
             U->prims4[i] = prepare_prim(lp[i]);
             flags &= U->prims4[i].flags;
         }
-        if ((flags & RM_SF_RCP) && !(flags & RM_SF_UNIT_SCALE))
-            for (int i = 0; i < 4; i++) {
-                U->prims4[i].sx = 1.0f / U->prims4[i].sx; U->prims4[i].sy = 1.0f / U->prims4[i].sy;
-                U->prims4[i].sz = 1.0f / U->prims4[i].sz;
-            }
         U->n_prims = 0;
     } else {
         size_t n = c->prims.size();
         std::vector<RmPrimDev> t(n);
         for (size_t i = 0; i < n; i++) { t[i] = prepare_prim(c->prims[i]); flags &= t[i].flags; }
-        if ((flags & RM_SF_RCP) && !(flags & RM_SF_UNIT_SCALE))
-            for (size_t i = 0; i < n; i++) { t[i].sx = 1.0f / t[i].sx; t[i].sy = 1.0f / t[i].sy; t[i].sz = 1.0f / t[i].sz; }
         if (c->prims_dirty || !c->d_prims) {
             int rc = ensure_cap(c, &c->d_prims, &c->d_prims_cap, n * sizeof(RmPrimDev));
             if (rc) return rc;

@@ -15,20 +15,20 @@ struct RmPrimDev {
     float ux, uy, uz;      // -q.xyz
     float c;               // q.w*q.w - dot(u,u)
     float w2;              // 2*q.w
-    float sx, sy, sz;      // scale, or its reciprocal when RM_PF_RCP is set
+    float sx, sy, sz;      // scale
     float ms;              // min(scale)
     float a0, a1, a2, a3;  // sphere: r*.5 | box: b*.5 | link: le,r1,r2 | cylinder: h,r | torus: t.x,t.y
     float cr, cg, cb;      // colour assigned after the primitive call (cginc:356-359)
     int32_t type;
     int32_t flags;
-    int32_t pad[3];
+    float rx, ry, rz;      // RN(1/scale), used when RM_PF_RCP is set
 };
 static_assert(sizeof(RmPrimDev) == 96, "RmPrimDev layout");
 
 enum : int32_t {
     RM_PF_IDENT_ROT  = 1,   // q == (0,0,0,1): rotate() returns its argument bit for bit
     RM_PF_UNIT_SCALE = 2,   // scale == (1,1,1): p/scale == p, d*min(scale) == d
-    RM_PF_RCP        = 4,   // every scale component is a power of two: p/s == p*(1/s) exactly
+    RM_PF_RCP        = 4,   // p/s may be computed from RN(1/s) with one exact residual correction (see rm_div_by)
 };
 
 // scene-wide specialisation, the AND of the per-primitive flags

@@ -233,7 +233,7 @@ RM_DI void rm_pixel(const RmParams &U, const S &sc) {
 // exactly once whatever the order, so the image does not depend on the history.
 //
 // Queue layout: [heavy tiles of the previous frame][static part][dynamic part].
-//  * wave w < n_heavy starts with heavy entry w, the others with their static share: every
+//  * wave w < min(n_heavy, n_waves) starts with heavy entry w, the others with their static share: every
 //    wave begins at t = 0 without touching a counter;
 //  * the static part (Q.static_per_wave entries per non-heavy wave, dealt cyclically) needs no
 //    atomics.  A device-scope returning atomic is a memory-side operation here (1-3 us, about
@@ -286,11 +286,14 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
     }
     __syncthreads();
 
-    const unsigned n_static_waves = n_waves > n_heavy ? n_waves - n_heavy : 0u;
-    const unsigned static_end = n_heavy + Q.static_per_wave * n_static_waves;      // <= n_entries by construction
+    // the first n_first heavy entries go one per wave; whatever the heavy list holds beyond the
+    // number of waves is served, like the image-order entries, through the static and dynamic parts
+    const unsigned n_first = n_heavy < n_waves ? n_heavy : n_waves;
+    const unsigned n_static_waves = n_waves - n_first;
+    const unsigned static_end = n_first + Q.static_per_wave * n_static_waves;      // <= n_entries by construction
     unsigned shard = blockIdx.x % RM_Q_SHARDS, dry = 0;      // dry: bit s set = shard s is exhausted
-    unsigned static_left = gw >= n_heavy ? Q.static_per_wave : 0u;
-    unsigned static_next = n_heavy + (gw - n_heavy);
+    unsigned static_left = gw >= n_first ? Q.static_per_wave : 0u;
+    unsigned static_next = n_first + (gw - n_first);
     unsigned dyn_left = 0, dyn_next = 0;
 
     // entry -> tile id, or 0xffffffff for an entry that must be skipped
@@ -312,7 +315,7 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
     auto chunk_first = [&](unsigned k, unsigned s) -> unsigned { return static_end + (k * RM_Q_SHARDS + s) * RM_Q_CHUNK; };
 
     bool done = false;
-    unsigned cur = gw < n_heavy ? gw : local_next();
+    unsigned cur = gw < n_first ? gw : local_next();
     if (cur == 0xffffffffu) {
         // no static share (tiny frame): first claim, synchronously
         unsigned k = 0;

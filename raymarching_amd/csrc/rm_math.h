@@ -9,7 +9,8 @@
 //     never feed .w, Assets/Raymarching.cginc:110-113),
 //   * k = .5 is a power of two, so 0.5*(b-a)/k == (b-a) and k*h == 0.5*h,
 //   * rotate() by the identity quaternion and a divide by a unit scale are
-//     skipped, a divide by a power-of-two scale is a multiply by its reciprocal.
+//     skipped; a divide by a (wave-uniform) scale uses its precomputed reciprocal plus one exact
+//     fma residual correction, which returns the correctly rounded quotient (rm_div_by).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "rm_device.h"
@@ -48,6 +49,18 @@ RM_DI V3 rm_normalize(V3 a) { float r = 1.0f / sqrtf(rm_dot3(a, a)); return mk3(
 // scale handling chosen per scene on the host
 enum { RM_SCL_UNIT = 0, RM_SCL_RCP = 1, RM_SCL_DIV = 2 };
 
+// x / s from r = RN(1/s):  q0 = x*r;  e = x - q0*s (exact, one fma);  q = q0 + e*r (one fma).
+// With a correctly rounded reciprocal this is the correctly rounded quotient (Markstein's
+// correction step); checked against IEEE division for every binary32 x in [2^-60, 2^60] and 100
+// divisors including all-ones and near-power-of-two significands (scripts/ubench/div_exhaustive.hip).
+// 3 full-rate VALU ops instead of the ~12 (one quarter-rate) of a correctly rounded divide.  The host
+// only selects it for normal scales with |exponent| <= 60 and a significand that is not all ones.
+RM_DI float rm_div_by(float x, float s, float r) {
+    float q0 = x * r;
+    float e = __builtin_fmaf(-q0, s, x);
+    return __builtin_fmaf(e, r, q0);
+}
+
 // p_i = rotate(p - pos, q) / scale        (cginc:336-354, rotate at :62-66)
 template <bool ROT, int SCL, class PT>
 RM_DI V3 rm_to_local(const PT &P, V3 p) {
@@ -60,7 +73,7 @@ RM_DI V3 rm_to_local(const PT &P, V3 p) {
                 (u.y * a + v.y * P.c) + cr.y * P.w2,
                 (u.z * a + v.z * P.c) + cr.z * P.w2);
     }
-    if (SCL == RM_SCL_RCP) v = mk3(v.x * P.sx, v.y * P.sy, v.z * P.sz);
+    if (SCL == RM_SCL_RCP) v = mk3(rm_div_by(v.x, P.sx, P.rx), rm_div_by(v.y, P.sy, P.ry), rm_div_by(v.z, P.sz, P.rz));
     if (SCL == RM_SCL_DIV) v = mk3(v.x / P.sx, v.y / P.sy, v.z / P.sz);
     return v;
 }
@@ -135,7 +148,7 @@ RM_DI float rm_vgpr(float s) {
 
 // vector-register copy of one prepared primitive (only the fields the variant reads)
 struct PrimV {
-    float px, py, pz, ux, uy, uz, c, w2, sx, sy, sz, ms, a0, a1, a2;
+    float px, py, pz, ux, uy, uz, c, w2, sx, sy, sz, rx, ry, rz, ms, a0, a1, a2;
 };
 template <bool ROT, int SCL>
 RM_DI PrimV rm_prim_to_vgpr(const RmPrimDev &P) {
@@ -146,6 +159,8 @@ RM_DI PrimV rm_prim_to_vgpr(const RmPrimDev &P) {
     else     { v.ux = v.uy = v.uz = v.c = v.w2 = 0.0f; }
     if (SCL != RM_SCL_UNIT) { v.sx = rm_vgpr(P.sx); v.sy = rm_vgpr(P.sy); v.sz = rm_vgpr(P.sz); v.ms = rm_vgpr(P.ms); }
     else                    { v.sx = v.sy = v.sz = v.ms = 1.0f; }
+    if (SCL == RM_SCL_RCP) { v.rx = rm_vgpr(P.rx); v.ry = rm_vgpr(P.ry); v.rz = rm_vgpr(P.rz); }
+    else                   { v.rx = v.ry = v.rz = 1.0f; }
     return v;
 }
 

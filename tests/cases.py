@@ -18,7 +18,7 @@ def _base(mat: Material, w: int, h: int, camera=None, transforms=None) -> Raymar
     return rm
 
 
-def transformed_transforms(pow2_scales: bool = False):
+def transformed_transforms(pow2_scales: bool = False, unsafe_scale: bool = False):
     """the four slots with rotations and non-unit scales (general rotate()/divide path)"""
     ts = scenes.default_transforms()
     rots = [quat_angle_axis(33.0, (1, 2, 3)), quat_angle_axis(-71.0, (0, 1, 1)),
@@ -26,6 +26,9 @@ def transformed_transforms(pow2_scales: bool = False):
     scl = [(1.3, 0.8, 1.1), (0.7, 1.9, 1.2), (0.9, 1.1, 1.05), (1.6, 0.6, 1.0)]
     if pow2_scales:
         scl = [(2.0, 1.0, 0.5), (0.5, 2.0, 1.0), (1.0, 1.0, 1.0), (2.0, 0.5, 1.0)]
+    if unsafe_scale:
+        # a significand of all ones is excluded from the reciprocal-based divide: true division path
+        scl = [(1.3, float(np.float32(1.9999999)), 1.1), (0.7, 1.9, 1.2), (0.9, 1.1, 1.05), (1.6, 0.6, 1.0)]
     for t, q, s in zip(ts, rots, scl):
         t.rotation = q.astype(F)
         t.lossyScale = np.asarray(s, dtype=F)
@@ -76,9 +79,9 @@ def _orbit(k):
     return f
 
 
-def _transformed(pow2):
+def _transformed(pow2, unsafe=False):
     def f(case, mat):
-        _base(mat, case.w, case.h, transforms=transformed_transforms(pow2))
+        _base(mat, case.w, case.h, transforms=transformed_transforms(pow2, unsafe))
     return f
 
 
@@ -126,6 +129,7 @@ CASES = [
     Case("orbit_k40_480x270", 480, 270, setup=_orbit(40)),
     Case("transformed_400x225", 400, 225, setup=_transformed(False)),
     Case("transformed_pow2_400x225", 400, 225, setup=_transformed(True)),
+    Case("transformed_truediv_400x225", 400, 225, setup=_transformed(False, True)),
     Case("fractional_steps_320x180", 320, 180, setup=_fractional_steps),
     Case("tiny_1x1", 1, 1),
     Case("tiny_17x3", 17, 3),

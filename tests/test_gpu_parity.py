@@ -218,6 +218,23 @@ def test_tile_history_does_not_change_output(oracle, torch_cuda, name):
                 assert got["stats"]["sum_steps_p"] == ref["stats"]["sum_steps_p"]
 
 
+def test_more_heavy_tiles_than_waves(oracle, torch_cuda):
+    """a frame with more tiles than resident waves and a threshold that puts (almost) every tile on the
+    heavy list: the part of the list beyond one entry per wave must still be rendered, exactly once"""
+    from raymarching_amd import Material, Raymarching, scenes
+    w, h = 1536, 864                      # 192 x 108 = 20736 tiles > 8192 list entries > 4096 waves
+    case = cases.Case("default_1536x864", w, h)
+    ref = cases.oracle_run(case, oracle)
+    with Material() as mat:
+        mat.set_kernel(KERNELS["queue"])
+        src, sd = case.bind(mat)
+        mat.SetFloat("_RmHeavyTileThreshold", 3.0)
+        for frame in range(3):
+            got = _render_once(case, torch_cuda, mat, src, sd, False)
+            assert_frame_equal(got, ref, f"frame {frame}")
+            assert got["stats"]["n_hit"] == ref["stats"]["n_hit"] and got["stats"]["sum_steps_p"] == ref["stats"]["sum_steps_p"]
+
+
 def test_repeat_runs_are_identical_and_counters_reset(torch_cuda):
     case = cases.BY_NAME["default_640x360"]
     a, b = gpu_run(case, torch_cuda), gpu_run(case, torch_cuda)
