@@ -313,6 +313,7 @@ int build_params(rm_ctx *c, RmParams *U, hipStream_t stream) {
         }
         U->prim_table = c->d_prims;
         U->n_prims = (int)n;
+        U->lds_prims = (n <= RM_LDS_PRIMS && getf(c, "_RmLdsTable", 1.0f) != 0.0f) ? (int)n : 0;
     }
     U->scene_flags = flags;
     return RM_OK;
@@ -410,7 +411,11 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream) {
 
 int launch(rm_ctx *c, const RmParams &U, hipStream_t stream) {
     RmParams P = U;
-    if (c->kernel == RM_KERNEL_TILE) {
+    // auto: the persistent queue kernel pays on the 4-slot scene, whose frames are a mass of cheap
+    // tiles plus a few long ones; N-primitive scenes are uniformly expensive per tile and run
+    // faster on the plain one-block-per-tile kernel (more registers free for the table walk)
+    const int kernel = c->kernel != RM_KERNEL_AUTO ? c->kernel : (U.n_prims > 0 ? RM_KERNEL_TILE : RM_KERNEL_QUEUE);
+    if (kernel == RM_KERNEL_TILE) {
         unsigned n_blocks = rm_tile_blocks(U.w, U.rows, U.n_poses);
         int rc = ensure_partials(c, n_blocks, stream);
         if (rc) return rc;

@@ -38,6 +38,8 @@ enum : int32_t {
     RM_SF_RCP        = 4,
 };
 
+#define RM_LDS_PRIMS 512       // largest primitive table staged in LDS (48 KB)
+
 struct RmView {
     float ro[3];           // _WorldSpaceCameraPos
     float bl[3], br[3], tl[3], tr[3];   // world-space corner rays: mul((float3x3)_CameraInvViewMatrix, _FrustrumCorners[i].xyz)
@@ -93,6 +95,7 @@ struct RmParams {
     int32_t  mode;
     int32_t  n_poses;
     int32_t  n_prims;          // 0: prims4 below
+    int32_t  lds_prims;        // n_prims if the table is staged in LDS by each workgroup, else 0
     int32_t  scene_flags;
     const RmView    *views;    // n_poses views, or nullptr
     const RmPrimDev *prim_table;

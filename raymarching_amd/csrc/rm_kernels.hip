@@ -249,7 +249,8 @@ RM_DI void rm_pixel(const RmParams &U, const S &sc) {
 // appended for the next frame, cleared for the one after.
 template <class S>
 RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
-    extern __shared__ unsigned s_bitmap[];
+    extern __shared__ __attribute__((aligned(16))) unsigned s_dyn[];
+    unsigned *s_bitmap = s_dyn + (size_t)U.lds_prims * (sizeof(RmPrimDev) / 4);      // after the staged primitive table, if any
     const RmQueue &Q = U.queue;
     const int lane = threadIdx.x & 63;
     const unsigned gw = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);   // global wave id
@@ -429,10 +430,31 @@ __global__ RM_LB void rm_tile_kernel4(const RmParams U) {
     rm_pixel(U, sc);
 }
 
+// The N-primitive table is staged into LDS once per workgroup (96 B per primitive, up to
+// RM_LDS_PRIMS of them): every lane then reads the same record, which the LDS serves as a
+// broadcast into VGPRs -- no scalar-load latency per primitive and no SGPR operands in the
+// distance arithmetic.  Larger tables are read from global memory through the scalar cache.
+RM_DI RmLdsPrimPtr rm_stage_table(const RmParams &U) {
+    extern __shared__ __attribute__((aligned(16))) unsigned s_dyn[];
+    const uint4 *src = reinterpret_cast<const uint4 *>(U.prim_table);
+    uint4 *dst = reinterpret_cast<uint4 *>(s_dyn);
+    const unsigned n16 = (unsigned)U.lds_prims * (sizeof(RmPrimDev) / 16);
+    for (unsigned i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+    return (RmLdsPrimPtr)(s_dyn);
+}
+
 template <bool ROT, int SCL>
 __global__ RM_LB void rm_tile_kernelN(const RmParams U) {
-    SceneN<ROT, SCL> sc(U.prim_table, U.n_prims);
-    rm_pixel(U, sc);
+    if (U.lds_prims) {
+        PrimTable<true> t; t.T = rm_stage_table(U);
+        SceneN<ROT, SCL, true> sc(t, U.n_prims);
+        rm_pixel(U, sc);
+    } else {
+        PrimTable<false> t; t.T = U.prim_table;
+        SceneN<ROT, SCL, false> sc(t, U.n_prims);
+        rm_pixel(U, sc);
+    }
 }
 
 // Waves per SIMD the register allocator is asked to fit.  4 (<= 128 VGPRs) is the measured best
@@ -454,9 +476,16 @@ __global__ RM_QLB void rm_queue_kernel4(const RmParams U) {
 }
 
 template <bool ROT, int SCL>
-__global__ RM_QLB void rm_queue_kernelN(const RmParams U) {
-    SceneN<ROT, SCL> sc(U.prim_table, U.n_prims);
-    rm_queue_body(U, sc);
+__global__ __launch_bounds__(256, RM_Q_MIN_WAVES) void rm_queue_kernelN(const RmParams U) {
+    if (U.lds_prims) {
+        PrimTable<true> t; t.T = rm_stage_table(U);
+        SceneN<ROT, SCL, true> sc(t, U.n_prims);
+        rm_queue_body(U, sc);
+    } else {
+        PrimTable<false> t; t.T = U.prim_table;
+        SceneN<ROT, SCL, false> sc(t, U.n_prims);
+        rm_queue_body(U, sc);
+    }
 }
 
 template <bool ROT, int SCL>
@@ -465,12 +494,12 @@ hipError_t launch_queue_variant(const RmParams &U, unsigned blocks, hipStream_t 
         int n4 = 0, nN = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, rm_queue_kernel4<ROT, SCL>, 256, (size_t)U.queue.bitmap_words * 4);
         if (e != hipSuccess) return e;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nN, rm_queue_kernelN<ROT, SCL>, 256, (size_t)U.queue.bitmap_words * 4);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nN, rm_queue_kernelN<ROT, SCL>, 256, (size_t)U.queue.bitmap_words * 4 + (size_t)U.lds_prims * sizeof(RmPrimDev));
         if (e != hipSuccess) return e;
         blocks_per_cu[0] = n4; blocks_per_cu[1] = nN;
         return hipSuccess;
     }
-    const size_t lds = (size_t)U.queue.bitmap_words * 4;
+    const size_t lds = (size_t)U.queue.bitmap_words * 4 + (size_t)U.lds_prims * sizeof(RmPrimDev);
     if (U.n_prims > 0) hipLaunchKernelGGL((rm_queue_kernelN<ROT, SCL>), dim3(blocks), dim3(256), lds, stream, U);
     else               hipLaunchKernelGGL((rm_queue_kernel4<ROT, SCL>), dim3(blocks), dim3(256), lds, stream, U);
     return hipGetLastError();
@@ -478,7 +507,7 @@ hipError_t launch_queue_variant(const RmParams &U, unsigned blocks, hipStream_t 
 
 template <bool ROT, int SCL>
 hipError_t launch_variant(const RmParams &U, dim3 grid, hipStream_t stream) {
-    if (U.n_prims > 0) hipLaunchKernelGGL((rm_tile_kernelN<ROT, SCL>), grid, dim3(RM_BLOCK), 0, stream, U);
+    if (U.n_prims > 0) hipLaunchKernelGGL((rm_tile_kernelN<ROT, SCL>), grid, dim3(RM_BLOCK), (size_t)U.lds_prims * sizeof(RmPrimDev), stream, U);
     else               hipLaunchKernelGGL((rm_tile_kernel4<ROT, SCL>), grid, dim3(RM_BLOCK), 0, stream, U);
     return hipGetLastError();
 }

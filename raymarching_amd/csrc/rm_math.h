@@ -201,62 +201,90 @@ struct Scene4 {
 // last element carried up) is evaluated in one pass with a binary-counter stack:
 // after primitive i, stack[l] holds the finished subtree of 2^l leaves iff bit l
 // of (i+1) is set; leftovers are merged low level first.
-#define RM_TREE_LEVELS 11
-template <bool ROT, int SCL>
-struct SceneN {
+typedef unsigned rm_u4 __attribute__((ext_vector_type(4)));
+typedef const rm_u4 __attribute__((address_space(3))) *RmLdsPrimPtr;      // the table as 16-byte words in LDS
+
+// fetches record i either from the LDS copy (ds_read broadcast into VGPRs) or from global
+// memory (wave-uniform address -> scalar cache)
+template <bool LDS> struct PrimTable;
+template <> struct PrimTable<true> {
+    RmLdsPrimPtr T;
+    RM_DI RmPrimDev get(int i) const {
+        union { RmPrimDev p; rm_u4 v[sizeof(RmPrimDev) / 16]; } u;
+#pragma unroll
+        for (int j = 0; j < (int)(sizeof(RmPrimDev) / 16); j++) u.v[j] = T[i * (int)(sizeof(RmPrimDev) / 16) + j];   // ds_read_b128, same address in every lane
+        return u.p;
+    }
+};
+template <> struct PrimTable<false> {
     const RmPrimDev *__restrict__ T;
+    RM_DI const RmPrimDev &get(int i) const { return T[i]; }
+};
+
+#define RM_ITEM_LEVELS 9      // binary-counter levels over groups of four leaves: 4 * 2^8 = 1024 primitives
+
+// N-primitive scene.  The balanced pairwise tree "in index order" (level by level, an odd
+// last element carried up unchanged) is evaluated in one pass over the table:
+//   * four consecutive leaves form one complete level-2 subtree smin(smin(a,b), smin(c,d)),
+//     evaluated straight-line (a trailing group of 1..3 leaves gives a, smin(a,b) or
+//     smin(smin(a,b), c) -- exactly what the carry rule makes of it);
+//   * the level-2 items are merged with a binary-counter stack: after item j, st[l] holds the
+//     finished subtree of 2^l items iff bit l of (j+1) is set; leftovers are merged low level
+//     first at the end, which reproduces the carry rule for any count.
+// All control flow is wave-uniform (every lane walks the same table), so it runs on the scalar
+// unit; grouping by four keeps that scalar work to a few instructions per primitive.
+template <bool ROT, int SCL, bool LDS>
+struct SceneN {
+    PrimTable<LDS> tab;
     int n;
-    RM_DI SceneN(const RmPrimDev *t, int n_) : T(t), n(n_) {}
-    RM_DI float w(V3 p) const {
-        float st[RM_TREE_LEVELS];
+    RM_DI SceneN(PrimTable<LDS> t, int n_) : tab(t), n(n_) {}
+
+    RM_DI float leaf_w(int i, V3 p) const {
+        const auto P = tab.get(i);
+        return rm_prim_typed<ROT, SCL>(P, P.type, p);
+    }
+    RM_DI V4 leaf4(int i, V3 p) const {
+        const auto P = tab.get(i);
+        V4 v;
+        v.w = rm_prim_typed<ROT, SCL>(P, P.type, p);
+        v.x = P.cr; v.y = P.cg; v.z = P.cb;
+        return v;
+    }
+    RM_DI static float comb(float a, float b) { return rm_smin_w(a, b); }
+    RM_DI static V4 comb(V4 a, V4 b) { return rm_smin4(a, b); }
+
+    template <class T, class LEAF>
+    RM_DI T tree(LEAF leaf) const {
+        T st[RM_ITEM_LEVELS];
+        const int groups = n >> 2, rem = n & 3;
+        for (int g = 0; g < groups; g++) {
+            const int i = g << 2;
+            T a = leaf(i), b = leaf(i + 1), c = leaf(i + 2), d = leaf(i + 3);
+            T v = comb(comb(a, b), comb(c, d));
+            const int merges = __builtin_ctz(~(unsigned)g);          // trailing ones of g = finished lower levels
 #pragma unroll
-        for (int l = 0; l < RM_TREE_LEVELS; l++) st[l] = 0.0f;
-        for (int i = 0; i < n; i++) {
-            const RmPrimDev &P = T[i];
-            float v = rm_prim_typed<ROT, SCL>(P, P.type, p);
-            bool placed = false;
+            for (int l = 0; l < RM_ITEM_LEVELS - 1; l++) if (l < merges) v = comb(st[l], v);
 #pragma unroll
-            for (int l = 0; l < RM_TREE_LEVELS; l++) {
-                if (!placed) {
-                    if (i & (1 << l)) v = rm_smin_w(st[l], v);
-                    else { st[l] = v; placed = true; }
-                }
-            }
+            for (int l = 0; l < RM_ITEM_LEVELS; l++) if (l == merges) st[l] = v;
         }
-        float acc = 0.0f;
+        int items = groups;
+        T acc = T();
         bool have = false;
+        if (rem) {
+            const int i = groups << 2;
+            acc = leaf(i);
+            if (rem >= 2) acc = comb(acc, leaf(i + 1));
+            if (rem == 3) acc = comb(acc, leaf(i + 2));
+            have = true;
+        }
 #pragma unroll
-        for (int l = 0; l < RM_TREE_LEVELS; l++) {
-            if (n & (1 << l)) { acc = have ? rm_smin_w(st[l], acc) : st[l]; have = true; }
+        for (int l = 0; l < RM_ITEM_LEVELS; l++) {
+            if (items & (1 << l)) { acc = have ? comb(st[l], acc) : st[l]; have = true; }
         }
         return acc;
     }
-    RM_DI V4 full(V3 p) const {
-        V4 st[RM_TREE_LEVELS];
-#pragma unroll
-        for (int l = 0; l < RM_TREE_LEVELS; l++) { st[l].x = st[l].y = st[l].z = st[l].w = 0.0f; }
-        for (int i = 0; i < n; i++) {
-            const RmPrimDev &P = T[i];
-            V4 v;
-            v.w = rm_prim_typed<ROT, SCL>(P, P.type, p);
-            v.x = P.cr; v.y = P.cg; v.z = P.cb;
-            bool placed = false;
-#pragma unroll
-            for (int l = 0; l < RM_TREE_LEVELS; l++) {
-                if (!placed) {
-                    if (i & (1 << l)) v = rm_smin4(st[l], v);
-                    else { st[l] = v; placed = true; }
-                }
-            }
-        }
-        V4 acc; acc.x = acc.y = acc.z = acc.w = 0.0f;
-        bool have = false;
-#pragma unroll
-        for (int l = 0; l < RM_TREE_LEVELS; l++) {
-            if (n & (1 << l)) { acc = have ? rm_smin4(st[l], acc) : st[l]; have = true; }
-        }
-        return acc;
-    }
+    RM_DI float w(V3 p) const { return tree<float>([&](int i) { return leaf_w(i, p); }); }
+    RM_DI V4 full(V3 p) const { return tree<V4>([&](int i) { return leaf4(i, p); }); }
 };
 
 RM_DI uint32_t rm_unorm8(float x) {
