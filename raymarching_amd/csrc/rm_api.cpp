@@ -339,7 +339,7 @@ int ensure_partials(rm_ctx *c, unsigned slots, hipStream_t stream) {
 }
 
 int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream) {
-    const uint32_t tx = (uint32_t)(P.w + 7) / 8, ty = (uint32_t)(P.rows + 7) / 8;
+    const uint32_t tx = (uint32_t)(P.w + RM_TW - 1) / RM_TW, ty = (uint32_t)(P.rows + RM_TH - 1) / RM_TH;
     const uint32_t n_tiles = tx * ty * (uint32_t)P.n_poses;
     const int vi = rm_variant_index(P), tab = P.n_prims > 0 ? 1 : 0;
     if (c->occ[vi][tab] == 0) {

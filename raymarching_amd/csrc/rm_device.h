@@ -50,6 +50,11 @@ static_assert(sizeof(RmView) == 64, "RmView layout");
 // Tile queue of the persistent kernel and its frame-to-frame state (all device memory owned
 // by the context).  Three heavy-list/bitmap sets and two counter sets rotate so that a frame
 // never clears anything it, or a concurrently running wave of the same frame, still reads.
+// pixel tile one wave renders at a time in the persistent kernel: RM_TW x RM_TH = 64
+#ifndef RM_TW
+#define RM_TW 8
+#endif
+#define RM_TH (64 / RM_TW)
 #define RM_Q_SHARDS 8
 #ifndef RM_Q_CHUNK
 #define RM_Q_CHUNK 4          // queue entries per dynamic claim

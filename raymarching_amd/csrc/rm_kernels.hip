@@ -250,7 +250,7 @@ RM_DI void rm_pixel(const RmParams &U, const S &sc) {
 template <class S>
 RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
     extern __shared__ __attribute__((aligned(16))) unsigned s_dyn[];
-    unsigned *s_bitmap = s_dyn + (size_t)U.lds_prims * (sizeof(RmPrimDev) / 4);      // after the staged primitive table, if any
+    unsigned *s_bitmap = s_dyn;      // the bitmap sits at LDS offset 0 (a compile-time address: a runtime offset here cost 8 %); a staged primitive table follows it
     const RmQueue &Q = U.queue;
     const int lane = threadIdx.x & 63;
     const unsigned gw = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);   // global wave id
@@ -348,7 +348,7 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
             const unsigned per_pose = Q.tiles_x * Q.tiles_y;
             const unsigned pose = tile / per_pose, t2 = tile - pose * per_pose;
             const unsigned ty = t2 / Q.tiles_x, tx = t2 - ty * Q.tiles_x;
-            const int x = (int)(tx * 8u) + (lane & 7), yl = (int)(ty * 8u) + (lane >> 3);
+            const int x = (int)(tx * RM_TW) + (lane % RM_TW), yl = (int)(ty * RM_TH) + (lane / RM_TW);
             if (x < U.w && yl < U.rows) { po = rm_compute_pixel(U, sc, x, yl, (int)pose, t_hit, t_p, t_s); have = true; }
             c_hit += t_hit; c_p += t_p; c_s += t_s;
         }
@@ -434,20 +434,21 @@ __global__ RM_LB void rm_tile_kernel4(const RmParams U) {
 // RM_LDS_PRIMS of them): every lane then reads the same record, which the LDS serves as a
 // broadcast into VGPRs -- no scalar-load latency per primitive and no SGPR operands in the
 // distance arithmetic.  Larger tables are read from global memory through the scalar cache.
-RM_DI RmLdsPrimPtr rm_stage_table(const RmParams &U) {
+RM_DI RmLdsPrimPtr rm_stage_table(const RmParams &U, unsigned lds_word_offset) {
     extern __shared__ __attribute__((aligned(16))) unsigned s_dyn[];
+    unsigned *base = s_dyn + lds_word_offset;
     const uint4 *src = reinterpret_cast<const uint4 *>(U.prim_table);
-    uint4 *dst = reinterpret_cast<uint4 *>(s_dyn);
+    uint4 *dst = reinterpret_cast<uint4 *>(base);
     const unsigned n16 = (unsigned)U.lds_prims * (sizeof(RmPrimDev) / 16);
     for (unsigned i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
-    return (RmLdsPrimPtr)(s_dyn);
+    return (RmLdsPrimPtr)(base);
 }
 
 template <bool ROT, int SCL>
 __global__ RM_LB void rm_tile_kernelN(const RmParams U) {
     if (U.lds_prims) {
-        PrimTable<true> t; t.T = rm_stage_table(U);
+        PrimTable<true> t; t.T = rm_stage_table(U, 0);
         SceneN<ROT, SCL, true> sc(t, U.n_prims);
         rm_pixel(U, sc);
     } else {
@@ -478,7 +479,7 @@ __global__ RM_QLB void rm_queue_kernel4(const RmParams U) {
 template <bool ROT, int SCL>
 __global__ __launch_bounds__(256, RM_Q_MIN_WAVES) void rm_queue_kernelN(const RmParams U) {
     if (U.lds_prims) {
-        PrimTable<true> t; t.T = rm_stage_table(U);
+        PrimTable<true> t; t.T = rm_stage_table(U, (U.queue.bitmap_words + 3u) & ~3u);
         SceneN<ROT, SCL, true> sc(t, U.n_prims);
         rm_queue_body(U, sc);
     } else {
@@ -494,12 +495,12 @@ hipError_t launch_queue_variant(const RmParams &U, unsigned blocks, hipStream_t 
         int n4 = 0, nN = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, rm_queue_kernel4<ROT, SCL>, 256, (size_t)U.queue.bitmap_words * 4);
         if (e != hipSuccess) return e;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nN, rm_queue_kernelN<ROT, SCL>, 256, (size_t)U.queue.bitmap_words * 4 + (size_t)U.lds_prims * sizeof(RmPrimDev));
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nN, rm_queue_kernelN<ROT, SCL>, 256, (size_t)((U.queue.bitmap_words + 3u) & ~3u) * 4 + (size_t)U.lds_prims * sizeof(RmPrimDev));
         if (e != hipSuccess) return e;
         blocks_per_cu[0] = n4; blocks_per_cu[1] = nN;
         return hipSuccess;
     }
-    const size_t lds = (size_t)U.queue.bitmap_words * 4 + (size_t)U.lds_prims * sizeof(RmPrimDev);
+    const size_t lds = (size_t)((U.queue.bitmap_words + 3u) & ~3u) * 4 + (size_t)U.lds_prims * sizeof(RmPrimDev);
     if (U.n_prims > 0) hipLaunchKernelGGL((rm_queue_kernelN<ROT, SCL>), dim3(blocks), dim3(256), lds, stream, U);
     else               hipLaunchKernelGGL((rm_queue_kernel4<ROT, SCL>), dim3(blocks), dim3(256), lds, stream, U);
     return hipGetLastError();
