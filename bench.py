@@ -59,6 +59,7 @@ def main() -> None:
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the RCCL gather of finished frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-gather", action="store_true", help="developer check: run the RCCL gather path with a single rank")
     ap.add_argument("--kernel", type=int, default=0, help="kernel variant (0 = auto)")
     args = ap.parse_args()
 
@@ -73,9 +74,12 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
-    if world > 1:
+    use_pg = world > 1 or args.force_gather
+    if use_pg:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
 
     from raymarching_amd import Material, Raymarching, scenes
     from raymarching_amd.distributed import PipelinedGather
@@ -92,8 +96,8 @@ def main() -> None:
     depth = torch.empty((h, w), dtype=torch.float32, device=dev)
     hit = torch.empty((h, w), dtype=torch.uint8, device=dev)
     like = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
-    gather = world > 1 and not args.no_gather
-    pipe = PipelinedGather(like, root=0, depth=2) if gather else None
+    gather = (world > 1 and not args.no_gather) or args.force_gather
+    pipe = PipelinedGather(like, root=0, depth=2, single_rank_too=args.force_gather) if gather else None
     single = like
     lib, ctx = mat._lib, mat.handle
 
@@ -106,7 +110,7 @@ def main() -> None:
     def fence() -> None:
         if pipe:
             pipe.drain()
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -172,7 +176,7 @@ def main() -> None:
         print(json.dumps(out), flush=True)
 
     mat.close()
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

@@ -69,6 +69,7 @@ struct rm_ctx {
     uint32_t q_last_tiles = 0, q_last_tx = 0, q_last_ty = 0; int q_last_mode = -1;
     int n_cus = 0;
     int occ[6][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};   // resident blocks per CU by kernel variant
+    int occ_stream[6][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
 
     hipStream_t last_stream = nullptr;
     uint64_t last_pixels = 0;
@@ -338,18 +339,19 @@ int ensure_partials(rm_ctx *c, unsigned slots, hipStream_t stream) {
     return ensure_cap(c, &c->d_partials, &c->d_partials_cap, bytes);
 }
 
-int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream) {
+int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, bool streamk) {
     const uint32_t tx = (uint32_t)(P.w + RM_TW - 1) / RM_TW, ty = (uint32_t)(P.rows + RM_TH - 1) / RM_TH;
     const uint32_t n_tiles = tx * ty * (uint32_t)P.n_poses;
     const int vi = rm_variant_index(P), tab = P.n_prims > 0 ? 1 : 0;
-    if (c->occ[vi][tab] == 0) {
+    int (*occ)[2] = streamk ? c->occ_stream : c->occ;
+    if (occ[vi][tab] == 0) {
         int o[2] = {0, 0};
-        RM_HIP(c, rm_launch_queue(P, 0, stream, o));
-        c->occ[vi][0] = o[0] > 0 ? o[0] : 1;
-        c->occ[vi][1] = o[1] > 0 ? o[1] : 1;
+        RM_HIP(c, streamk ? rm_launch_stream(P, 0, stream, o) : rm_launch_queue(P, 0, stream, o));
+        occ[vi][0] = o[0] > 0 ? o[0] : 1;
+        occ[vi][1] = o[1] > 0 ? o[1] : 1;
     }
     // the heavy bitmap lives in LDS: keep history only while it fits comfortably beside 4+ blocks per CU
-    const bool keep_history = n_tiles <= RM_QUEUE_MAX_TILES;
+    const bool keep_history = !streamk && n_tiles <= RM_QUEUE_MAX_TILES;
     const uint32_t bm_words = keep_history ? (n_tiles + 31) / 32 : 0;
     if (!c->d_queue || bm_words > c->q_bm_cap) {
         RM_HIP(c, hipStreamSynchronize(stream));
@@ -393,7 +395,7 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream) {
     c->q_last_mode = keep_history ? P.mode : -1;
     c->q_last_tiles = n_tiles; c->q_last_tx = tx; c->q_last_ty = ty;
 
-    unsigned resident = (unsigned)c->n_cus * (unsigned)c->occ[vi][tab];
+    unsigned resident = (unsigned)c->n_cus * (unsigned)occ[vi][tab];
     unsigned want = (n_tiles + 3) / 4;
     unsigned blocks = want < resident ? want : resident;
     // static share: a fraction of the tiles, dealt evenly over the waves that will not start on a
@@ -404,7 +406,7 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream) {
     int rc = ensure_partials(c, blocks * 4, stream);
     if (rc) return rc;
     P.partials = c->d_partials;
-    RM_HIP(c, rm_launch_queue(P, blocks, stream, nullptr));
+    RM_HIP(c, streamk ? rm_launch_stream(P, blocks, stream, nullptr) : rm_launch_queue(P, blocks, stream, nullptr));
     c->last_blocks = blocks * 4;
     return RM_OK;
 }
@@ -423,7 +425,7 @@ int launch(rm_ctx *c, const RmParams &U, hipStream_t stream) {
         RM_HIP(c, rm_launch_tiles(P, stream));
         c->last_blocks = n_blocks;
     } else {
-        int rc = launch_queue(c, P, stream);
+        int rc = launch_queue(c, P, stream, kernel == RM_KERNEL_STREAM);
         if (rc) return rc;
     }
     c->last_stream = stream;
@@ -538,7 +540,7 @@ int rm_set_primitives(rm_ctx *c, const rm_primitive *prims, int n) {
 
 int rm_set_kernel(rm_ctx *c, int variant) {
     if (!c) return RM_E_ARG;
-    if (variant != RM_KERNEL_AUTO && variant != RM_KERNEL_TILE && variant != RM_KERNEL_QUEUE) return fail(c, RM_E_ARG, "unknown kernel variant");
+    if (variant != RM_KERNEL_AUTO && variant != RM_KERNEL_TILE && variant != RM_KERNEL_QUEUE && variant != RM_KERNEL_STREAM) return fail(c, RM_E_ARG, "unknown kernel variant");
     c->kernel = variant;
     return RM_OK;
 }

@@ -83,25 +83,18 @@ RM_DI float rm_getshadow(const S &sc, V3 p, V3 n, V3 L, float contact, float dep
 
 struct PixelOut { uint32_t rgba; float depth; uint32_t hit; size_t oidx; };
 
-// The whole fragment program for one pixel (x, local row yl, pose): primary march, and for a
-// hit pixel the six normal taps, the colour evaluation, the shadow march and the shade
-// (shader:149-216).  Miss pixels skip normal/shadow: the shader computes and then discards
-// them (shader:197-202).  Adds this pixel's counts to c_hit / c_p / c_s.  Nothing is
-// stored here: the caller decides when the framebuffer writes are issued.
-template <class S>
-RM_DI PixelOut rm_compute_pixel(const RmParams &U, const S &sc, int x, int yl, int pose,
-                                unsigned &c_hit, unsigned &c_p, unsigned &c_s) {
-    PixelOut out;
+// Ray of pixel (x, local row yl, pose): origin, un-normalised direction, march depth limit,
+// and the pixel's index in the full frame (inputs) and in the compact output.
+RM_DI void rm_setup_ray(const RmParams &U, int x, int yl, int pose, V3 &ro, V3 &rd, float &depth, size_t &gidx, size_t &oidx) {
     // compact local row -> frame row (row-band shard; identity when n_parts == 1)
     const int band = yl / U.band_rows;
     const int y = (band * U.n_parts + U.part) * U.band_rows + (yl - band * U.band_rows);
-    const size_t gidx = (size_t)y * (size_t)U.w + (size_t)x;                    // full-frame index
-    out.oidx = ((size_t)pose * (size_t)U.rows + (size_t)yl) * (size_t)U.w + (size_t)x;
+    gidx = (size_t)y * (size_t)U.w + (size_t)x;
+    oidx = ((size_t)pose * (size_t)U.rows + (size_t)yl) * (size_t)U.w + (size_t)x;
 
     const RmView &V = U.views ? U.views[pose] : U.view;
     const float uu = ((float)x + 0.5f) / (float)U.w;
     const float vv = ((float)y + 0.5f) / (float)U.h;
-    V3 ro, rd;
     if (U.mode == RM_MODE_DEPTH_ORTHO) {
         V3 c0 = mk3(U.ortho_c[0][0], U.ortho_c[0][1], U.ortho_c[0][2]);
         V3 c1 = mk3(U.ortho_c[1][0], U.ortho_c[1][1], U.ortho_c[1][2]);
@@ -116,10 +109,25 @@ RM_DI PixelOut rm_compute_pixel(const RmParams &U, const S &sc, int x, int yl, i
         ro = mk3(rm_vgpr(V.ro[0]), rm_vgpr(V.ro[1]), rm_vgpr(V.ro[2]));
         rd = rm_lerp3(rm_lerp3(bl, br, uu), rm_lerp3(tl, tr, uu), vv);
     }
-
-    float depth = U.far_plane;                                    // shader:154
+    depth = U.far_plane;                                          // shader:154
     if (U.mode == RM_MODE_FRAG && U.sdepth) depth = U.sdepth[gidx];
     depth = fminf(depth, U.max_dist);                             // cginc:368
+}
+
+
+// The whole fragment program for one pixel (x, local row yl, pose): primary march, and for a
+// hit pixel the six normal taps, the colour evaluation, the shadow march and the shade
+// (shader:149-216).  Miss pixels skip normal/shadow: the shader computes and then discards
+// them (shader:197-202).  Adds this pixel's counts to c_hit / c_p / c_s.  Nothing is
+// stored here: the caller decides when the framebuffer writes are issued.
+template <class S>
+RM_DI PixelOut rm_compute_pixel(const RmParams &U, const S &sc, int x, int yl, int pose,
+                                unsigned &c_hit, unsigned &c_p, unsigned &c_s) {
+    PixelOut out;
+    V3 ro, rd;
+    float depth;
+    size_t gidx;
+    rm_setup_ray(U, x, yl, pose, ro, rd, depth, gidx, out.oidx);
 
     const float sf = rm_vgpr(U.step_factor);
     MarchResult r = rm_raymarch(sc, ro, rd, depth, U.n_steps, sf);
@@ -405,6 +413,180 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
     }
 }
 
+// ---- kernel C: persistent waves with lane-level ray compaction ---------------------------
+// Every lane carries one ray through a small state machine; one loop iteration is one scene
+// evaluation for every busy lane, whatever that lane is doing: a primary step, one of the six
+// normal taps (evaluated as o + d*t with d = +-axis, t = epsilon, which is hp +- e exactly) or
+// a shadow step.  A lane whose pixel is finished goes idle and is refilled with the next pixel
+// of the wave's current 8x8 tile as soon as RM_S_REFILL_MIN lanes are idle (a ballot), so a
+// wave stays full while single rays of it run long.  The per-ray arithmetic is the same as in
+// the tile kernels; only the interleaving differs, so the image is bit-identical.
+//
+// The colour evaluation (scene().rgb, a full blend tree) is the one step that is not a plain
+// distance evaluation: lanes reaching it wait until RM_S_SHADE_MIN of them can share one
+// divergent pass (or nothing else is left to do).
+//
+// Pays where one evaluation is expensive and step counts diverge (N-primitive scenes): the
+// state handling is a few dozen instructions per iteration.  Tiles are claimed dynamically
+// (first tile = wave index, then an atomic counter): a tile is milliseconds of work there.
+#ifndef RM_S_REFILL_MIN
+#define RM_S_REFILL_MIN 8
+#endif
+#ifndef RM_S_SHADE_MIN
+#define RM_S_SHADE_MIN 8
+#endif
+enum { RM_PH_IDLE = 0, RM_PH_PRIMARY = 1, RM_PH_TAP = 2, RM_PH_WAITCOL = 3, RM_PH_SHADOW = 4 };
+
+template <class S>
+RM_DI void rm_stream_body(const RmParams &U, const S &sc) {
+    const RmQueue &Q = U.queue;
+    const int lane = threadIdx.x & 63;
+    const unsigned gw = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const unsigned n_waves = (gridDim.x * blockDim.x) >> 6;
+    unsigned *counter = Q.counters + Q.cnt_cur * RM_Q_SHARDS * RM_Q_STRIDE;
+    if (gw == 0 && lane < RM_Q_SHARDS) Q.counters[(Q.cnt_clr * RM_Q_SHARDS + lane) * RM_Q_STRIDE] = 0u;
+
+    const float sf = rm_vgpr(U.step_factor), kc = rm_vgpr(.0025f), eps = rm_vgpr(U.nss);
+    const V3 L = mk3(rm_vgpr(U.light[0]), rm_vgpr(U.light[1]), rm_vgpr(U.light[2]));
+    const unsigned per_pose = Q.tiles_x * Q.tiles_y;
+
+    // per-lane ray state
+    int phase = RM_PH_IDLE, cnt = 0, tap = 0;
+    V3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), raw = mk3(0, 0, 0), base = mk3(0, 0, 0);
+    float t = 0.0f, lim = 0.0f, res = 1.0f, contact = 0.0f, tmp = 0.0f, ao = 0.0f, length = 0.0f;
+    size_t gidx = 0, oidx = 0;
+    unsigned c_hit = 0, c_p = 0, c_s = 0;
+
+    unsigned tile = gw < Q.n_tiles ? gw : 0xffffffffu, next_px = 0;
+
+    for (;;) {
+        // ---- refill idle lanes from the current tile ------------------------------------
+        const unsigned long long idle = __ballot(phase == RM_PH_IDLE);
+        if (tile != 0xffffffffu && (__popcll(idle) >= RM_S_REFILL_MIN || idle == ~0ull)) {
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+            const unsigned px = next_px + rank;
+            if (phase == RM_PH_IDLE && px < 64u) {
+                const unsigned pose = tile / per_pose, t2 = tile - pose * per_pose;
+                const unsigned ty = t2 / Q.tiles_x, tx = t2 - ty * Q.tiles_x;
+                const int x = (int)(tx * 8u + (px & 7u)), yl = (int)(ty * 8u + (px >> 3));
+                if (x < U.w && yl < U.rows) {
+                    rm_setup_ray(U, x, yl, (int)pose, o, d, lim, gidx, oidx);
+                    t = 0.0f; cnt = U.n_steps; contact = 0.0f;
+                    phase = RM_PH_PRIMARY;
+                    if (cnt <= 0) {                       // _MaxSteps <= 0: the loop body never runs, a miss of length 0
+                        length = 0.0f;
+                        phase = RM_PH_IDLE;
+                        PixelOut po; po.oidx = oidx; po.depth = 0.0f; po.hit = 0;
+                        po.rgba = U.src ? (reinterpret_cast<const uint32_t *>(U.src)[gidx] | 0xFF000000u) : U.bg_rgba8;
+                        rm_store_pixel(U, po);
+                    }
+                }
+            }
+            unsigned taken = (unsigned)__popcll(idle);
+            taken = taken < 64u - next_px ? taken : 64u - next_px;
+            next_px += taken;
+            if (next_px == 64u) {
+                unsigned kq = 0;
+                if (lane == 0) kq = atomicAdd(counter, 1u);
+                kq = __builtin_amdgcn_readfirstlane(kq);
+                tile = n_waves + kq;
+                if (tile >= Q.n_tiles) tile = 0xffffffffu;
+                next_px = 0;
+            }
+        }
+
+        const bool marching = phase == RM_PH_PRIMARY || phase == RM_PH_TAP || phase == RM_PH_SHADOW;
+        const unsigned long long m_mask = __ballot(marching);
+        const unsigned long long w_mask = __ballot(phase == RM_PH_WAITCOL);
+        if (!m_mask && !w_mask) {
+            if (tile == 0xffffffffu) break;
+            continue;                                     // only idle lanes: refill again
+        }
+
+        // ---- one scene evaluation for every marching lane --------------------------------
+        if (marching) {
+            const float dts = sc.w(mk3(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t));
+            if (phase == RM_PH_TAP) {
+                // taps come in +/- pairs: x+, x-, y+, y-, z+, z-  (shader:63-67)
+                if (!(tap & 1)) tmp = dts;
+                else {
+                    const float df = tmp - dts;
+                    raw.x = tap == 1 ? df : raw.x; raw.y = tap == 3 ? df : raw.y; raw.z = tap == 5 ? df : raw.z;
+                }
+                tap++;
+                if (tap == 6) phase = RM_PH_WAITCOL;
+                else {
+                    const float sg = (tap & 1) ? -1.0f : 1.0f;
+                    d = mk3((tap >> 1) == 0 ? sg : 0.0f, (tap >> 1) == 1 ? sg : 0.0f, (tap >> 1) == 2 ? sg : 0.0f);
+                }
+            } else {
+                if (phase == RM_PH_SHADOW) { res = fminf(res, 16.0f * dts / t); c_s++; }      // shader:111
+                else c_p++;
+                const float a = fabsf(dts);
+                t += a * sf;
+                contact = t * kc;
+                cnt--;
+                const bool touch = a < contact;
+                if (touch || t > lim || cnt == 0) {
+                    if (phase == RM_PH_PRIMARY) {
+                        length = t;
+                        if (touch && U.mode == RM_MODE_FRAG) {
+                            // hit: on to the normal taps around hp = ro + rd * r.length (shader:174)
+                            c_hit++;
+                            o = mk3(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t);
+                            d = mk3(1.0f, 0.0f, 0.0f);
+                            t = eps; tap = 0;
+                            phase = RM_PH_TAP;
+                        } else {
+                            if (touch) c_hit++;
+                            PixelOut po; po.oidx = oidx; po.depth = t; po.hit = touch ? 1u : 0u;
+                            po.rgba = U.src ? (reinterpret_cast<const uint32_t *>(U.src)[gidx] | 0xFF000000u) : U.bg_rgba8;
+                            rm_store_pixel(U, po);
+                            phase = RM_PH_IDLE;
+                        }
+                    } else {
+                        // shadow march finished: shade and write (shader:195-199)
+                        const float shadow = res * 0.75f + .25f;
+                        PixelOut po; po.oidx = oidx; po.depth = length; po.hit = 1u;
+                        po.rgba = rm_unorm8((base.x * shadow) * ao) | (rm_unorm8((base.y * shadow) * ao) << 8) |
+                                  (rm_unorm8((base.z * shadow) * ao) << 16) | 0xFF000000u;
+                        rm_store_pixel(U, po);
+                        phase = RM_PH_IDLE;
+                    }
+                }
+            }
+        }
+
+        // ---- colour + shading set-up for lanes that finished their taps, in batches ----------
+        const unsigned long long w2 = __ballot(phase == RM_PH_WAITCOL);
+        const unsigned long long m2 = __ballot(phase == RM_PH_PRIMARY || phase == RM_PH_TAP || phase == RM_PH_SHADOW);
+        if (w2 && (__popcll(w2) >= RM_S_SHADE_MIN || (!m2 && (tile == 0xffffffffu || __popcll(__ballot(phase == RM_PH_IDLE)) < RM_S_REFILL_MIN)))) {
+            if (phase == RM_PH_WAITCOL) {
+                const V3 n = rm_normalize(raw);
+                const V4 s = sc.full(o);                                                          // shader:193, o == hitpoint
+                const float ndl = rm_dot3(n, L) * .5f + .5f;
+                ao = rm_clamp01(rm_len3(mk3(raw.x / U.nss_raw, raw.y / U.nss_raw, raw.z / U.nss_raw)));   // shader:125-127
+                base = mk3(s.x * ndl, s.y * ndl, s.z * ndl);
+                // getshadow: start at p + n * _ContactThreshold * 2 with the threshold raymarch() left (shader:107)
+                const float c0 = length * kc;
+                o = mk3(o.x + (n.x * c0) * 2.0f, o.y + (n.y * c0) * 2.0f, o.z + (n.z * c0) * 2.0f);
+                d = L;
+                t = 0.0f; res = 1.0f; lim = U.shadow_depth; cnt = U.n_steps;
+                phase = RM_PH_SHADOW;
+            }
+        }
+    }
+
+    c_hit = rm_wave_sum(c_hit); c_p = rm_wave_sum(c_p); c_s = rm_wave_sum(c_s);
+    if (lane == 0) {
+        unsigned *out = U.partials + RM_SLOT_WORDS * gw;
+        out[0] = c_hit; out[1] = c_p; out[2] = c_s;
+#ifdef RM_TIMELINE
+        out[3] = out[4] = out[5] = out[6] = out[7] = 0;
+#endif
+    }
+}
+
 // sums the per-block counter slots of the last launch: out[0..2] = n_hit, primary evals, shadow evals
 __global__ __launch_bounds__(1024) void rm_reduce_stats_kernel(const unsigned *__restrict__ partials, unsigned n_blocks,
                                                                unsigned long long *__restrict__ out) {
@@ -490,6 +672,42 @@ __global__ __launch_bounds__(256, RM_Q_MIN_WAVES) void rm_queue_kernelN(const Rm
 }
 
 template <bool ROT, int SCL>
+__global__ __launch_bounds__(256, RM_Q_MIN_WAVES) void rm_stream_kernelN(const RmParams U) {
+    if (U.lds_prims) {
+        PrimTable<true> t; t.T = rm_stage_table(U, 0);
+        SceneN<ROT, SCL, true> sc(t, U.n_prims);
+        rm_stream_body(U, sc);
+    } else {
+        PrimTable<false> t; t.T = U.prim_table;
+        SceneN<ROT, SCL, false> sc(t, U.n_prims);
+        rm_stream_body(U, sc);
+    }
+}
+
+template <bool ROT, int SCL>
+__global__ __launch_bounds__(256, (ROT ? RM_Q_MIN_WAVES_ROT : RM_Q_MIN_WAVES)) void rm_stream_kernel4(const RmParams U) {
+    Scene4<ROT, SCL> sc(U);
+    rm_stream_body(U, sc);
+}
+
+template <bool ROT, int SCL>
+hipError_t launch_stream_variant(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu) {
+    const size_t lds = (size_t)U.lds_prims * sizeof(RmPrimDev);
+    if (blocks_per_cu) {
+        int n4 = 0, nN = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, rm_stream_kernel4<ROT, SCL>, 256, 0);
+        if (e != hipSuccess) return e;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nN, rm_stream_kernelN<ROT, SCL>, 256, lds);
+        if (e != hipSuccess) return e;
+        blocks_per_cu[0] = n4; blocks_per_cu[1] = nN;
+        return hipSuccess;
+    }
+    if (U.n_prims > 0) hipLaunchKernelGGL((rm_stream_kernelN<ROT, SCL>), dim3(blocks), dim3(256), lds, stream, U);
+    else               hipLaunchKernelGGL((rm_stream_kernel4<ROT, SCL>), dim3(blocks), dim3(256), 0, stream, U);
+    return hipGetLastError();
+}
+
+template <bool ROT, int SCL>
 hipError_t launch_queue_variant(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu) {
     if (blocks_per_cu) {
         int n4 = 0, nN = 0;
@@ -544,6 +762,19 @@ hipError_t rm_launch_queue(const RmParams &U, unsigned blocks, hipStream_t strea
     if (scl == RM_SCL_UNIT) return launch_queue_variant<false, RM_SCL_UNIT>(U, blocks, stream, blocks_per_cu);
     if (scl == RM_SCL_RCP)  return launch_queue_variant<false, RM_SCL_RCP>(U, blocks, stream, blocks_per_cu);
     return launch_queue_variant<false, RM_SCL_DIV>(U, blocks, stream, blocks_per_cu);
+}
+
+hipError_t rm_launch_stream(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu) {
+    bool rot; int scl;
+    variant_index(U, rot, scl);
+    if (rot) {
+        if (scl == RM_SCL_UNIT) return launch_stream_variant<true, RM_SCL_UNIT>(U, blocks, stream, blocks_per_cu);
+        if (scl == RM_SCL_RCP)  return launch_stream_variant<true, RM_SCL_RCP>(U, blocks, stream, blocks_per_cu);
+        return launch_stream_variant<true, RM_SCL_DIV>(U, blocks, stream, blocks_per_cu);
+    }
+    if (scl == RM_SCL_UNIT) return launch_stream_variant<false, RM_SCL_UNIT>(U, blocks, stream, blocks_per_cu);
+    if (scl == RM_SCL_RCP)  return launch_stream_variant<false, RM_SCL_RCP>(U, blocks, stream, blocks_per_cu);
+    return launch_stream_variant<false, RM_SCL_DIV>(U, blocks, stream, blocks_per_cu);
 }
 
 int rm_variant_index(const RmParams &U) { bool r; int s; return variant_index(U, r, s); }

@@ -102,15 +102,16 @@ class PipelinedGather:
         g.drain()
     """
 
-    def __init__(self, like: torch.Tensor, root: int = 0, group=None, depth: int = 2):
+    def __init__(self, like: torch.Tensor, root: int = 0, group=None, depth: int = 2, single_rank_too: bool = False):
         self.root, self.group = root, group
+        self.single_rank_too = single_rank_too      # run the collective even with one rank (exercises the stream logic)
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.bufs = [torch.empty_like(like) for _ in range(depth)]
         self.cuda = like.is_cuda
         self.side = torch.cuda.Stream(device=like.device) if self.cuda else None
         self.done = [None] * depth          # event: gather of bufs[i] finished
         self.recv = None
-        if self.rank == root and self.world > 1:
+        if self.rank == root and (self.world > 1 or single_rank_too):
             self.recv = [[torch.empty_like(like) for _ in range(self.world)] for _ in range(depth)]
         self.i = 0
 
@@ -123,7 +124,7 @@ class PipelinedGather:
     def submit(self, buf: torch.Tensor) -> None:
         k = self.i % len(self.bufs)
         self.i += 1
-        if self.world == 1:
+        if self.world == 1 and not self.single_rank_too:
             return
         if not self.cuda:
             dist.gather(buf, self.recv[k] if self.recv else None, dst=self.root, group=self.group)

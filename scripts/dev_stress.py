@@ -19,7 +19,7 @@ def timeit(mat, w, h, n=20):
     return e0.elapsed_time(e1) / n, mat.stats()
 
 w, h = 1920, 1080
-for kernel in (1, 2):
+for kernel in (1, 2, 3):
     with Material() as mat:
         mat.set_kernel(kernel)
         rm = Raymarching(scenes.stress_camera(w, h), mat, scenes.default_transforms()); rm.bind()

@@ -27,7 +27,7 @@ def torch_cuda():
     return torch
 
 
-KERNELS = {"tile": 1, "queue": 2}
+KERNELS = {"tile": 1, "queue": 2, "stream": 3}
 
 
 def gpu_run(case, torch, host_path=False, kernel=0, frames=1):
@@ -83,7 +83,7 @@ def _render_once(case, torch, mat, src, sd, host_path):
         return {"rgba": rt.color.cpu().numpy(), "depth": rt.depth.cpu().numpy(), "hit": rt.hit.cpu().numpy(), "stats": st}
 
 
-@pytest.mark.parametrize("kernel", ["tile", "queue"])
+@pytest.mark.parametrize("kernel", ["tile", "queue", "stream"])
 @pytest.mark.parametrize("name", [c.name for c in cases.CASES if not c.heavy])
 def test_gpu_equals_oracle(oracle, torch_cuda, name, kernel):
     case = cases.BY_NAME[name]
@@ -100,7 +100,7 @@ def test_gpu_equals_oracle(oracle, torch_cuda, name, kernel):
     assert got["stats"]["n_pixels"] == case.w * case.h
 
 
-@pytest.mark.parametrize("kernel,frames", [("tile", 1), ("queue", 1), ("queue", 4)])
+@pytest.mark.parametrize("kernel,frames", [("tile", 1), ("queue", 1), ("queue", 4), ("stream", 2)])
 @pytest.mark.parametrize("name", ["default_1920x1080", "default_3840x2160"])
 def test_gpu_full_size_matches_golden_hashes(torch_cuda, name, kernel, frames):
     """BASELINE sizes (1080p, 4K) against the oracle's committed hashes; with frames > 1 the
