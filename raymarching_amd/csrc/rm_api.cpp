@@ -395,7 +395,10 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, bool streamk) {
     c->q_last_mode = keep_history ? P.mode : -1;
     c->q_last_tiles = n_tiles; c->q_last_tx = tx; c->q_last_ty = ty;
 
-    unsigned resident = (unsigned)c->n_cus * (unsigned)occ[vi][tab];
+    unsigned per_cu = (unsigned)occ[vi][tab];
+    const float cap_per_cu = getf(c, "_RmBlocksPerCU", 0.0f);      // 0: as many as fit
+    if (cap_per_cu >= 1.0f && (unsigned)cap_per_cu < per_cu) per_cu = (unsigned)cap_per_cu;
+    unsigned resident = (unsigned)c->n_cus * per_cu;
     unsigned want = (n_tiles + 3) / 4;
     unsigned blocks = want < resident ? want : resident;
     // static share: a fraction of the tiles, dealt evenly over the waves that will not start on a
