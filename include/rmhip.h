@@ -46,12 +46,19 @@ typedef struct rm_ctx rm_ctx;
  * torus is the reference's unused fifth primitive (cginc:179-182) */
 enum { RM_SPHERE = 0, RM_BOX = 1, RM_LINK = 2, RM_CYLINDER = 3, RM_TORUS = 4 };
 
+/* op bits of a primitive.  The scene is the pairwise tree of cginc:363 in index order; each of
+ * its nodes has exactly one primitive that is the first one of its right operand, and that
+ * primitive's RM_OP_SMAX bit makes the node smax (Assets/Raymarching.cginc:120-123) instead of
+ * smin (:110-113).  RM_OP_NEGATE flips the sign of the primitive's distance (its complement), so
+ * smax with a negated primitive carves it out of what stands to its left. */
+enum { RM_OP_SMAX = 1, RM_OP_NEGATE = 2 };
+
 /* One scene primitive for rm_set_primitives(): generalises the four rows of
  * _Positions/_Rotations/_Scales (Assets/Raymarching.cs:58-83) beyond the
  * reference's 4-slot limit (Assets/Raymarching.cs:60). */
 typedef struct {
     int32_t type;       /* RM_* */
-    int32_t op;         /* reserved, 0 = smooth union (smin, cginc:110-113) */
+    int32_t op;         /* RM_OP_* bits, 0 = smooth union */
     float   pos[3];
     float   quat[4];    /* x,y,z,w */
     float   scale[3];
@@ -100,7 +107,9 @@ int rm_has_property(rm_ctx *ctx, const char *name);
 
 /* N-primitive scene (n = 0 returns to the 4-row matrices).  Extends
  * GetPositions/GetRotations/GetScales (Assets/Raymarching.cs:58-83); the tree is
- * the balanced pairwise smin of Assets/Raymarching.cginc:363 in index order. */
+ * the balanced pairwise smin of Assets/Raymarching.cginc:363 in index order (level by level,
+ * an odd last element carried up), with smax nodes and negated primitives where the op bits
+ * ask for them. */
 int rm_set_primitives(rm_ctx *ctx, const rm_primitive *prims, int n);
 
 /* ---- Graphics.Blit(src, dest, mat) --------------------------------------

@@ -85,6 +85,12 @@ def smin_w(a, b, k=.5):                           # cginc:110-113, distance lane
     return lerp(b, a, h) - k * h * (f(1) - h), h
 
 
+def smax_w(a, b, k=.5):                           # cginc:120-123, distance lane
+    k = f(k)
+    h = clamp(f(.5) + f(.5) * (a - b) / k, 0, 1)
+    return -lerp(-b, -a, h) - k * h * (f(1) - h), h
+
+
 def blend(c1, c2, h):                             # cginc:101-103
     mx, my, mz = lerp(c1[0], c2[0], h), lerp(c1[1], c2[1], h), lerp(c1[2], c2[2], h)
     inv = f(1) / np.sqrt(dot(mx, my, mz, mx, my, mz))
@@ -125,29 +131,32 @@ class Scene:
             d = cylinder(lx, ly, lz, a[0], a[1])
         else:
             d = torus(lx, ly, lz, a[0], a[1])
-        return d * np.fmin(s[0], np.fmin(s[1], s[2]))
+        d = d * np.fmin(s[0], np.fmin(s[1], s[2]))
+        return -d if int(p.get("op", 0)) & 2 else d            # NEGATE bit: complement solid
 
     def eval(self, x, y, z, want_rgb=False):
-        """cginc:334-364: balanced pairwise smin level by level in index order."""
-        items = []
-        for p in self.prims:
-            d = self.prim(p, x, y, z)
-            if want_rgb:
-                c = tuple(np.full_like(d, p["color"][j]) for j in range(3))
+        """cginc:334-364 generalised: the pairwise tree in index order with an odd element carried
+        up is the left-complete tree -- a node over n leaves has the largest power of two below n
+        leaves on its left.  A node is smax (cginc:120-123) when the first leaf of its right
+        operand carries the SMAX bit, smin (cginc:110-113) otherwise."""
+        def node(lo, hi):
+            if hi - lo == 1:
+                p = self.prims[lo]
+                d = self.prim(p, x, y, z)
+                c = tuple(np.full_like(d, p["color"][j]) for j in range(3)) if want_rgb else None
+                return c, d
+            split = 1
+            while split * 2 < hi - lo:
+                split *= 2
+            (ca, a), (cb, b) = node(lo, lo + split), node(lo + split, hi)
+            if int(self.prims[lo + split].get("op", 0)) & 1:
+                w, h = smax_w(a, b)
+                c = tuple(lerp(cb[j], ca[j], h) for j in range(3)) if want_rgb else None
             else:
-                c = None
-            items.append((c, d))
-        while len(items) > 1:
-            nxt = []
-            for i in range(0, len(items) - 1, 2):
-                (ca, a), (cb, b) = items[i], items[i + 1]
                 w, h = smin_w(a, b)
                 c = blend(cb, ca, h) if want_rgb else None
-                nxt.append((c, w))
-            if len(items) & 1:
-                nxt.append(items[-1])
-            items = nxt
-        return items[0]
+            return c, w
+        return node(0, len(self.prims))
 
 
 def march(scene, ox, oy, oz, dx, dy, dz, depth, steps, sf, shadow=False):

@@ -107,6 +107,15 @@ static inline f4 smin4(f4 a, f4 b, float k) {
     return r;
 }
 
+/* ---- cginc:120-123  smax(float4,float4,k): plain lerp of rgb, and the reference's
+ * sign of the k*h*(1-h) term (subtracted, as in smin) ----------------------- */
+static inline f4 smax4(f4 a, f4 b, float k) {
+    float h = clamp1(0.5f + 0.5f * (a.w - b.w) / k, 0.0f, 1.0f);
+    f3 c = lerp3(xyz(b), xyz(a), h);
+    f4 r = {c.x, c.y, c.z, -lerp1(-b.w, -a.w, h) - k * h * (1.0f - h)};
+    return r;
+}
+
 /* primitive wrapper: p_i = rotate(p - pos, q);  o = prim(p_i / scale) * min(scale)
  * (cginc:336-354) */
 static inline float prim_dist(const rmo_prim *pr, f3 p) {
@@ -122,7 +131,8 @@ static inline float prim_dist(const rmo_prim *pr, f3 p) {
     case RMO_CYLINDER: d = sd_cylinder(pl, pr->params[0], pr->params[1]); break;
     default:           d = sd_torus(pl, pr->params[0], pr->params[1]); break;
     }
-    return d * min3(s);
+    d = d * min3(s);
+    return (pr->op & RMO_OP_NEGATE) ? -d : d;
 }
 
 /* the reference's fixed scene as a primitive table: sphere, box, link(5,5,.1),
@@ -160,17 +170,23 @@ typedef struct {
  * order; an odd element at the end of a level is carried up unchanged. */
 static inline f4 scene(const scene_ctx *c, f3 p) {
     f4 o[RMO_MAX_PRIMS];
+    int first[RMO_MAX_PRIMS];          /* leftmost leaf under each node: its op bits choose the merge */
     int n = c->n;
     for (int i = 0; i < n; i++) {
         const rmo_prim *pr = &c->prims[i];
         o[i].w = prim_dist(pr, p);
         o[i].x = pr->color[0]; o[i].y = pr->color[1]; o[i].z = pr->color[2];
+        first[i] = i;
     }
     float k = c->u->smooth_k;
     while (n > 1) {
         int m = 0;
-        for (int i = 0; i + 1 < n; i += 2) o[m++] = smin4(o[i], o[i + 1], k);
-        if (n & 1) o[m++] = o[n - 1];
+        for (int i = 0; i + 1 < n; i += 2) {
+            int smax = c->prims[first[i + 1]].op & RMO_OP_SMAX;
+            first[m] = first[i];
+            o[m++] = smax ? smax4(o[i], o[i + 1], k) : smin4(o[i], o[i + 1], k);
+        }
+        if (n & 1) { first[m] = first[n - 1]; o[m++] = o[n - 1]; }
         n = m;
     }
     return o[0];
@@ -180,17 +196,24 @@ static inline f4 scene(const scene_ctx *c, f3 p) {
  * reads rgb, so dropping the colour blend changes no bit of the result */
 static inline float scene_w(const scene_ctx *c, f3 p) {
     float o[RMO_MAX_PRIMS];
+    int first[RMO_MAX_PRIMS];
     int n = c->n;
-    for (int i = 0; i < n; i++) o[i] = prim_dist(&c->prims[i], p);
+    for (int i = 0; i < n; i++) { o[i] = prim_dist(&c->prims[i], p); first[i] = i; }
     float k = c->u->smooth_k;
     while (n > 1) {
         int m = 0;
         for (int i = 0; i + 1 < n; i += 2) {
             float a = o[i], b = o[i + 1];
-            float h = clamp1(0.5f + 0.5f * (b - a) / k, 0.0f, 1.0f);
-            o[m++] = lerp1(b, a, h) - k * h * (1.0f - h);
+            first[m] = first[i];
+            if (c->prims[first[i + 1]].op & RMO_OP_SMAX) {
+                float h = clamp1(0.5f + 0.5f * (a - b) / k, 0.0f, 1.0f);
+                o[m++] = -lerp1(-b, -a, h) - k * h * (1.0f - h);
+            } else {
+                float h = clamp1(0.5f + 0.5f * (b - a) / k, 0.0f, 1.0f);
+                o[m++] = lerp1(b, a, h) - k * h * (1.0f - h);
+            }
         }
-        if (n & 1) o[m++] = o[n - 1];
+        if (n & 1) { first[m] = first[n - 1]; o[m++] = o[n - 1]; }
         n = m;
     }
     return o[0];
@@ -485,6 +508,11 @@ void rmo_rotate_q(const float v[3], const float q[4], float out[3]) {
     out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
 float rmo_remap(float x, float o1, float o2, float n1, float n2) { return remap(x, o1, o2, n1, n2); }
+void rmo_smax4(const float a[4], const float b[4], float k, float out[4]) {
+    f4 aa = {a[0], a[1], a[2], a[3]}, bb = {b[0], b[1], b[2], b[3]};
+    f4 r = smax4(aa, bb, k);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
 void rmo_smin4(const float a[4], const float b[4], float k, float out[4]) {
     f4 aa = {a[0], a[1], a[2], a[3]}, bb = {b[0], b[1], b[2], b[3]};
     f4 r = smin4(aa, bb, k);

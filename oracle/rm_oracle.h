@@ -32,11 +32,15 @@ extern "C" {
 /* primitive kinds, in the order scene() uses them (Assets/Raymarching.cginc:351-354) */
 enum { RMO_SPHERE = 0, RMO_BOX = 1, RMO_LINK = 2, RMO_CYLINDER = 3, RMO_TORUS = 4 };
 /* combine operator applied when a primitive's subtree is merged upwards */
-enum { RMO_OP_SMIN = 0, RMO_OP_SMAX = 1 };
+/* op bits of a primitive.  Every internal node of the pairwise tree has exactly one leaf that
+ * is the leftmost leaf of its right operand; that leaf's SMAX bit chooses smax (cginc:120-123)
+ * over smin (cginc:110-113) for the node.  NEGATE flips the sign of the primitive's distance
+ * (the complement solid), so smax with a negated primitive is a smooth subtraction. */
+enum { RMO_OP_SMIN = 0, RMO_OP_SMAX = 1, RMO_OP_NEGATE = 2 };
 
 typedef struct {
     int32_t type;       /* RMO_* */
-    int32_t op;         /* RMO_OP_* (reserved; smooth union only for now) */
+    int32_t op;         /* RMO_OP_* bits */
     float   pos[3];     /* _Positions row   (Assets/Raymarching.cs:61) */
     float   quat[4];    /* _Rotations row x,y,z,w (Assets/Raymarching.cs:71) */
     float   scale[3];   /* _Scales row      (Assets/Raymarching.cs:79) */
@@ -103,6 +107,7 @@ float rmo_torus(const float p[3], float tx, float ty);
 void  rmo_rotate_q(const float v[3], const float q[4], float out[3]);
 float rmo_remap(float x, float o1, float o2, float n1, float n2);
 void  rmo_smin4(const float a[4], const float b[4], float k, float out[4]);
+void  rmo_smax4(const float a[4], const float b[4], float k, float out[4]);
 void  rmo_scene(const rmo_uniforms *u, const float p[3], float out[4]);
 void  rmo_pixel_ray(const rmo_uniforms *u, int x, int y, int w, int h, float rd[3]);
 int   rmo_vert_corner_index(float uvx, float uvy);

@@ -77,6 +77,8 @@ def lib() -> C.CDLL:
         l.rmo_remap.argtypes = [C.c_float] * 5
         l.rmo_smin4.restype = None
         l.rmo_smin4.argtypes = [FP, FP, C.c_float, FP]
+        l.rmo_smax4.restype = None
+        l.rmo_smax4.argtypes = [FP, FP, C.c_float, FP]
         l.rmo_scene.restype = None
         l.rmo_scene.argtypes = [UP, FP, FP]
         l.rmo_pixel_ray.restype = None

@@ -180,7 +180,7 @@ uint32_t unorm8(float x) {
 }
 
 // evaluates the uniform-only parts of the scene() wrapper (cginc:62-66,336-354)
-RmPrimDev prepare_prim(const rm_primitive &p) {
+RmPrimDev prepare_prim(const rm_primitive &p, int *flags_out) {
     RmPrimDev d;
     std::memset(&d, 0, sizeof d);
     d.px = p.pos[0]; d.py = p.pos[1]; d.pz = p.pos[2];
@@ -194,7 +194,7 @@ RmPrimDev prepare_prim(const rm_primitive &p) {
     switch (p.type) {
     case RM_SPHERE: d.a0 = p.params[0] * .5f; break;
     case RM_BOX:    d.a0 = p.params[0] * .5f; d.a1 = p.params[1] * .5f; d.a2 = p.params[2] * .5f; break;
-    default:        d.a0 = p.params[0]; d.a1 = p.params[1]; d.a2 = p.params[2]; d.a3 = p.params[3]; break;
+    default:        d.a0 = p.params[0]; d.a1 = p.params[1]; d.a2 = p.params[2]; break;
     }
     int flags = 0;
     if (p.quat[0] == 0.0f && p.quat[1] == 0.0f && p.quat[2] == 0.0f && p.quat[3] == 1.0f) flags |= RM_PF_IDENT_ROT;
@@ -203,7 +203,10 @@ RmPrimDev prepare_prim(const rm_primitive &p) {
         flags |= RM_PF_RCP;
         d.rx = 1.0f / p.scale[0]; d.ry = 1.0f / p.scale[1]; d.rz = 1.0f / p.scale[2];
     }
-    d.flags = flags;
+    if (p.op & (RM_OP_SMAX | RM_OP_NEGATE)) flags |= RM_PF_CSG;
+    *flags_out = flags;
+    d.nsgn = (p.op & RM_OP_NEGATE) ? -1.0f : 1.0f;
+    d.osgn = (p.op & RM_OP_SMAX) ? -1.0f : 1.0f;
     d.sx = p.scale[0]; d.sy = p.scale[1]; d.sz = p.scale[2];
     return d;
 }
@@ -295,14 +298,47 @@ int build_params(rm_ctx *c, RmParams *U, hipStream_t stream) {
         rm_primitive lp[4];
         legacy_prims(c, lp);
         for (int i = 0; i < 4; i++) {
-            U->prims4[i] = prepare_prim(lp[i]);
-            flags &= U->prims4[i].flags;
+            int pf = 0;
+            U->prims4[i] = prepare_prim(lp[i], &pf);
+            flags &= pf;
         }
         U->n_prims = 0;
     } else {
         size_t n = c->prims.size();
         std::vector<RmPrimDev> t(n);
-        for (size_t i = 0; i < n; i++) { t[i] = prepare_prim(c->prims[i]); flags &= t[i].flags; }
+        bool csg = false;
+        for (size_t i = 0; i < n; i++) {
+            int pf = 0;
+            t[i] = prepare_prim(c->prims[i], &pf);
+            flags &= pf;
+            csg = csg || (pf & RM_PF_CSG);
+        }
+        if (csg) {
+            // The kernel walks the table in groups of four and merges finished groups with a
+            // binary-counter stack.  A node's op is the SMAX bit of the leftmost primitive of its
+            // right operand: inside a group those records are at hand; for the stack merges the bits
+            // are gathered here, into record 4g for the cascade after group g and into tail_ops for
+            // the final low-to-high merge of the leftovers.
+            auto smax_at = [&](size_t prim) { return (c->prims[prim].op & RM_OP_SMAX) ? 1u : 0u; };
+            const size_t groups = n >> 2, rem = n & 3;
+            for (size_t g = 0; g < groups; g++) {
+                uint32_t bits = 0;
+                for (unsigned l = 0; l < 9 && ((g >> l) & 1u); l++)          // trailing ones of g
+                    bits |= smax_at(4 * (g - ((size_t)1 << l) + 1)) << l;     // v covers groups g-2^l+1 .. g
+                t[4 * g].type |= (int32_t)(bits << RM_CASCADE_SHIFT);
+            }
+            uint32_t tail = 0;
+            bool have = rem != 0;
+            size_t acc_first = 4 * groups;
+            for (unsigned l = 0; l < 9; l++) {
+                if (!(groups & ((size_t)1 << l))) continue;
+                if (have) tail |= smax_at(acc_first) << l;
+                acc_first = 4 * (groups & ~(((size_t)2 << l) - 1));
+                have = true;
+            }
+            U->tail_ops = tail;
+            flags |= RM_SF_CSG;
+        }
         if (c->prims_dirty || !c->d_prims) {
             int rc = ensure_cap(c, &c->d_prims, &c->d_prims_cap, n * sizeof(RmPrimDev));
             if (rc) return rc;
@@ -534,7 +570,7 @@ int rm_set_primitives(rm_ctx *c, const rm_primitive *prims, int n) {
     if (!c || n < 0 || (n > 0 && !prims)) return fail(c, RM_E_ARG, "rm_set_primitives: bad argument");
     if (n > RM_MAX_PRIMS) return fail(c, RM_E_RANGE, "more than RM_MAX_PRIMS primitives");
     for (int i = 0; i < n; i++)
-        if (prims[i].type < RM_SPHERE || prims[i].type > RM_TORUS || prims[i].op != 0)
+        if (prims[i].type < RM_SPHERE || prims[i].type > RM_TORUS || (prims[i].op & ~(RM_OP_SMAX | RM_OP_NEGATE)) != 0)
             return fail(c, RM_E_ARG, "rm_set_primitives: unknown primitive type or operator");
     c->prims.assign(prims, prims + n);
     c->prims_dirty = true;

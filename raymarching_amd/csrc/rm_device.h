@@ -17,10 +17,12 @@ struct RmPrimDev {
     float w2;              // 2*q.w
     float sx, sy, sz;      // scale
     float ms;              // min(scale)
-    float a0, a1, a2, a3;  // sphere: r*.5 | box: b*.5 | link: le,r1,r2 | cylinder: h,r | torus: t.x,t.y
+    float a0, a1, a2;      // sphere: r*.5 | box: b*.5 | link: le,r1,r2 | cylinder: h,r | torus: t.x,t.y
+    float nsgn;            // -1 if the distance is negated (complement solid), else +1
     float cr, cg, cb;      // colour assigned after the primitive call (cginc:356-359)
-    int32_t type;
-    int32_t flags;
+    int32_t type;          // bits 0-7: primitive kind.  In records 4g, bit 8+l: the merge of group g's
+                           // finished subtree with stack level l is smax (see SceneN::tree)
+    float osgn;            // -1 if the node whose right operand starts at this primitive is smax, else +1
     float rx, ry, rz;      // RN(1/scale), used when RM_PF_RCP is set
 };
 static_assert(sizeof(RmPrimDev) == 96, "RmPrimDev layout");
@@ -28,6 +30,7 @@ static_assert(sizeof(RmPrimDev) == 96, "RmPrimDev layout");
 enum : int32_t {
     RM_PF_IDENT_ROT  = 1,   // q == (0,0,0,1): rotate() returns its argument bit for bit
     RM_PF_UNIT_SCALE = 2,   // scale == (1,1,1): p/scale == p, d*min(scale) == d
+    RM_PF_CSG        = 8,   // carries an op bit (host-side bookkeeping only)
     RM_PF_RCP        = 4,   // p/s may be computed from RN(1/s) with one exact residual correction (see rm_div_by)
 };
 
@@ -36,7 +39,11 @@ enum : int32_t {
     RM_SF_IDENT_ROT  = 1,
     RM_SF_UNIT_SCALE = 2,
     RM_SF_RCP        = 4,
+    RM_SF_CSG        = 8,   // some primitive carries an op bit (smax node or negated distance)
 };
+
+#define RM_TYPE_MASK 0xff
+#define RM_CASCADE_SHIFT 8
 
 #define RM_LDS_PRIMS 512       // largest primitive table staged in LDS (48 KB)
 
@@ -102,6 +109,7 @@ struct RmParams {
     int32_t  n_prims;          // 0: prims4 below
     int32_t  lds_prims;        // n_prims if the table is staged in LDS by each workgroup, else 0
     int32_t  scene_flags;
+    uint32_t tail_ops;       // bit l: the final merge with stack level l is smax (see SceneN::tree)
     const RmView    *views;    // n_poses views, or nullptr
     const RmPrimDev *prim_table;
     const uint8_t   *src;      // full-frame RGBA8 or nullptr

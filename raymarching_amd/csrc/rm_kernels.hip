@@ -631,11 +631,11 @@ template <bool ROT, int SCL>
 __global__ RM_LB void rm_tile_kernelN(const RmParams U) {
     if (U.lds_prims) {
         PrimTable<true> t; t.T = rm_stage_table(U, 0);
-        SceneN<ROT, SCL, true> sc(t, U.n_prims);
+        SceneN<ROT, SCL, true> sc(t, U.n_prims, (U.scene_flags & RM_SF_CSG) != 0, U.tail_ops);
         rm_pixel(U, sc);
     } else {
         PrimTable<false> t; t.T = U.prim_table;
-        SceneN<ROT, SCL, false> sc(t, U.n_prims);
+        SceneN<ROT, SCL, false> sc(t, U.n_prims, (U.scene_flags & RM_SF_CSG) != 0, U.tail_ops);
         rm_pixel(U, sc);
     }
 }
@@ -662,11 +662,11 @@ template <bool ROT, int SCL>
 __global__ __launch_bounds__(256, RM_Q_MIN_WAVES) void rm_queue_kernelN(const RmParams U) {
     if (U.lds_prims) {
         PrimTable<true> t; t.T = rm_stage_table(U, (U.queue.bitmap_words + 3u) & ~3u);
-        SceneN<ROT, SCL, true> sc(t, U.n_prims);
+        SceneN<ROT, SCL, true> sc(t, U.n_prims, (U.scene_flags & RM_SF_CSG) != 0, U.tail_ops);
         rm_queue_body(U, sc);
     } else {
         PrimTable<false> t; t.T = U.prim_table;
-        SceneN<ROT, SCL, false> sc(t, U.n_prims);
+        SceneN<ROT, SCL, false> sc(t, U.n_prims, (U.scene_flags & RM_SF_CSG) != 0, U.tail_ops);
         rm_queue_body(U, sc);
     }
 }
@@ -675,11 +675,11 @@ template <bool ROT, int SCL>
 __global__ __launch_bounds__(256, RM_Q_MIN_WAVES) void rm_stream_kernelN(const RmParams U) {
     if (U.lds_prims) {
         PrimTable<true> t; t.T = rm_stage_table(U, 0);
-        SceneN<ROT, SCL, true> sc(t, U.n_prims);
+        SceneN<ROT, SCL, true> sc(t, U.n_prims, (U.scene_flags & RM_SF_CSG) != 0, U.tail_ops);
         rm_stream_body(U, sc);
     } else {
         PrimTable<false> t; t.T = U.prim_table;
-        SceneN<ROT, SCL, false> sc(t, U.n_prims);
+        SceneN<ROT, SCL, false> sc(t, U.n_prims, (U.scene_flags & RM_SF_CSG) != 0, U.tail_ops);
         rm_stream_body(U, sc);
     }
 }

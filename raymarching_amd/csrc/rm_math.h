@@ -123,6 +123,17 @@ RM_DI V4 rm_smin4(V4 a, V4 b) {
     return r;
 }
 
+// smax(float4 a, float4 b, .5)  (cginc:120-123): plain lerp of rgb; the k*h*(1-h) term keeps the
+// reference's sign
+RM_DI V4 rm_smax4(V4 a, V4 b) {
+    float h = rm_clamp01(0.5f + (a.w - b.w));
+    V3 c = rm_lerp3(mk3(b.x, b.y, b.z), mk3(a.x, a.y, a.z), h);
+    V4 r;
+    r.x = c.x; r.y = c.y; r.z = c.z;
+    r.w = -rm_lerp(-b.w, -a.w, h) - (0.5f * h) * (1.0f - h);
+    return r;
+}
+
 template <bool ROT, int SCL, class PT>
 RM_DI float rm_prim_typed(const PT &P, int type, V3 p) {
     V3 l = rm_to_local<ROT, SCL>(P, p);
@@ -237,33 +248,54 @@ template <bool ROT, int SCL, bool LDS>
 struct SceneN {
     PrimTable<LDS> tab;
     int n;
-    RM_DI SceneN(PrimTable<LDS> t, int n_) : tab(t), n(n_) {}
+    bool csg;              // some primitive carries an op bit
+    uint32_t tail_ops;
+    RM_DI SceneN(PrimTable<LDS> t, int n_, bool csg_, uint32_t tail_ops_) : tab(t), n(n_), csg(csg_), tail_ops(tail_ops_) {}
 
-    RM_DI float leaf_w(int i, V3 p) const {
+    // leaf value plus what the tree needs from the record: osgn (the op of the node this leaf
+    // opens as leftmost leaf of a right operand) and the type word with the cascade bits
+    template <bool CSG>
+    RM_DI float leaf_w(int i, V3 p, float &osgn, int &tw) const {
         const auto P = tab.get(i);
-        return rm_prim_typed<ROT, SCL>(P, P.type, p);
+        float d = rm_prim_typed<ROT, SCL>(P, P.type & RM_TYPE_MASK, p);
+        if (CSG) { d = d * P.nsgn; osgn = P.osgn; tw = P.type; }       // x * -1 == -x exactly
+        return d;
     }
-    RM_DI V4 leaf4(int i, V3 p) const {
+    template <bool CSG>
+    RM_DI V4 leaf4(int i, V3 p, float &osgn, int &tw) const {
         const auto P = tab.get(i);
         V4 v;
-        v.w = rm_prim_typed<ROT, SCL>(P, P.type, p);
+        v.w = rm_prim_typed<ROT, SCL>(P, P.type & RM_TYPE_MASK, p);
+        if (CSG) { v.w = v.w * P.nsgn; osgn = P.osgn; tw = P.type; }
         v.x = P.cr; v.y = P.cg; v.z = P.cb;
         return v;
     }
-    RM_DI static float comb(float a, float b) { return rm_smin_w(a, b); }
-    RM_DI static V4 comb(V4 a, V4 b) { return rm_smin4(a, b); }
+    // node of the tree: s = +1 smin (cginc:110-113), s = -1 smax (cginc:120-123); s is wave-uniform
+    template <bool CSG> RM_DI static float comb(float a, float b, float s) {
+        if (!CSG) return rm_smin_w(a, b);
+        float e = b - a;
+        float h = rm_clamp01(0.5f + e * s);          // smax: 0.5 + (a - b), and a - b == -(b - a) exactly
+        return (b - h * e) - (0.5f * h) * (1.0f - h);
+    }
+    template <bool CSG> RM_DI static V4 comb(V4 a, V4 b, float s) {
+        if (!CSG || s > 0.0f) return rm_smin4(a, b);
+        return rm_smax4(a, b);
+    }
 
-    template <class T, class LEAF>
+    template <class T, bool CSG, class LEAF>
     RM_DI T tree(LEAF leaf) const {
         T st[RM_ITEM_LEVELS];
         const int groups = n >> 2, rem = n & 3;
         for (int g = 0; g < groups; g++) {
             const int i = g << 2;
-            T a = leaf(i), b = leaf(i + 1), c = leaf(i + 2), d = leaf(i + 3);
-            T v = comb(comb(a, b), comb(c, d));
+            float s0 = 1.0f, sb = 1.0f, sc = 1.0f, sd = 1.0f;
+            int tw = 0, t1 = 0;
+            T a = leaf(i, s0, tw), b = leaf(i + 1, sb, t1), c = leaf(i + 2, sc, t1), d = leaf(i + 3, sd, t1);
+            T v = comb<CSG>(comb<CSG>(a, b, sb), comb<CSG>(c, d, sd), sc);
             const int merges = __builtin_ctz(~(unsigned)g);          // trailing ones of g = finished lower levels
 #pragma unroll
-            for (int l = 0; l < RM_ITEM_LEVELS - 1; l++) if (l < merges) v = comb(st[l], v);
+            for (int l = 0; l < RM_ITEM_LEVELS - 1; l++)
+                if (l < merges) v = comb<CSG>(st[l], v, (CSG && ((tw >> (RM_CASCADE_SHIFT + l)) & 1)) ? -1.0f : 1.0f);
 #pragma unroll
             for (int l = 0; l < RM_ITEM_LEVELS; l++) if (l == merges) st[l] = v;
         }
@@ -272,19 +304,30 @@ struct SceneN {
         bool have = false;
         if (rem) {
             const int i = groups << 2;
-            acc = leaf(i);
-            if (rem >= 2) acc = comb(acc, leaf(i + 1));
-            if (rem == 3) acc = comb(acc, leaf(i + 2));
+            float s0 = 1.0f, sb = 1.0f, sc = 1.0f;
+            int t1 = 0;
+            acc = leaf(i, s0, t1);
+            if (rem >= 2) { T b = leaf(i + 1, sb, t1); acc = comb<CSG>(acc, b, sb); }
+            if (rem == 3) { T c = leaf(i + 2, sc, t1); acc = comb<CSG>(acc, c, sc); }
             have = true;
         }
 #pragma unroll
         for (int l = 0; l < RM_ITEM_LEVELS; l++) {
-            if (items & (1 << l)) { acc = have ? comb(st[l], acc) : st[l]; have = true; }
+            if (items & (1 << l)) {
+                acc = have ? comb<CSG>(st[l], acc, (CSG && ((tail_ops >> l) & 1u)) ? -1.0f : 1.0f) : st[l];
+                have = true;
+            }
         }
         return acc;
     }
-    RM_DI float w(V3 p) const { return tree<float>([&](int i) { return leaf_w(i, p); }); }
-    RM_DI V4 full(V3 p) const { return tree<V4>([&](int i) { return leaf4(i, p); }); }
+    RM_DI float w(V3 p) const {
+        if (csg) return tree<float, true>([&](int i, float &s, int &tw) { return leaf_w<true>(i, p, s, tw); });
+        return tree<float, false>([&](int i, float &s, int &tw) { return leaf_w<false>(i, p, s, tw); });
+    }
+    RM_DI V4 full(V3 p) const {
+        if (csg) return tree<V4, true>([&](int i, float &s, int &tw) { return leaf4<true>(i, p, s, tw); });
+        return tree<V4, false>([&](int i, float &s, int &tw) { return leaf4<false>(i, p, s, tw); });
+    }
 };
 
 RM_DI uint32_t rm_unorm8(float x) {

@@ -97,6 +97,50 @@ def stress_primitives(n: int = 256, seed: int = 0x5EED0256) -> List[dict]:
     return out
 
 
+OP_SMAX, OP_NEGATE = 1, 2      # rm_primitive.op bits
+
+
+def csg_primitives() -> List[dict]:
+    """Seven primitives in front of the default camera that use every op: a box with a sphere
+    carved out, a cylinder intersected with a sphere, a torus joined to a link, the whole clipped by
+    a large sphere.  Tree (index order, odd element carried): (((0,1),(2,3)), ((4,5),6))."""
+    q0 = [0.0, 0.0, 0.0, 1.0]
+    q1 = [float(v) for v in quat_angle_axis(25.0, (0, 1, 0))]
+    q2 = [float(v) for v in quat_angle_axis(-40.0, (1, 0, 1))]
+
+    def prim(t, op, pos, quat, scale, color, params):
+        return {"type": t, "op": op, "pos": [float(F(v)) for v in pos], "quat": [float(F(v)) for v in quat],
+                "scale": [float(F(v)) for v in scale], "color": color, "params": params}
+    return [
+        prim(1, 0, (-1.4, 0.6, 0.0), q1, (1, 1, 1), (1.0, 0.4, 0.3), (2.0, 2.0, 2.0)),
+        prim(0, OP_SMAX | OP_NEGATE, (-1.1, 0.9, -0.7), q0, (1, 1, 1), (0.3, 0.9, 1.0), (2.2,)),
+        prim(3, 0, (-4.2, 0.2, 0.3), q2, (1.5, 1.2, 1.5), (0.9, 0.9, 0.3), (0.5, 0.5)),
+        prim(0, OP_SMAX, (-4.2, 0.5, 0.3), q0, (1, 1, 1), (0.4, 1.0, 0.4), (1.9,)),
+        prim(4, 0, (-7.0, 0.6, 1.0), q2, (2, 2, 2), (0.5, 0.5, 1.0), (0.5, 0.25)),
+        prim(2, 0, (-7.87, 0.0, 1.522), q0, (1, 1, 1), (0.25, 0.25, 1.0), (5.0, 5.0, 0.1)),
+        prim(0, OP_SMAX, (-4.0, 0.5, 0.5), q0, (1, 1, 1), (1.0, 1.0, 1.0), (13.0,)),
+    ]
+
+
+def csg_random_primitives(n: int, seed: int = 0x5EEDC56) -> List[dict]:
+    """stress_primitives(n) with op bits that reach every kind of node of the tree walk while
+    leaving something to see: primitives 0..7 stay a union (1 carved out of 0, 4 intersected with
+    5); everything from 8 on is negated and joined by smax at the power-of-two boundaries (so
+    it only carves), with further smax nodes at random (1 in 8) inside."""
+    out = stress_primitives(n, seed)
+    rng = SplitMix64(seed ^ 0xC56C56)
+    for i, p in enumerate(out):
+        u = rng.uniform()
+        if i >= 8:
+            boundary = (i & (i - 1)) == 0 or (i == 4 * (n // 4) and n % 4 != 0)
+            p["op"] = OP_NEGATE | (OP_SMAX if (boundary or u < 0.125) else 0)
+    if n > 1:
+        out[1]["op"] = OP_SMAX | OP_NEGATE
+    if n > 5:
+        out[5]["op"] = OP_SMAX
+    return out
+
+
 def stress_camera(width: int = 1920, height: int = 1080) -> Camera:
     """Camera at (0, .75, -14) pitched 2 degrees down: grazing rays over the slab."""
     rot = quat_angle_axis(2.0, (1, 0, 0))

@@ -141,6 +141,9 @@ CASES = [
         {"type": 2, "pos": (-7.87, 0.0, 1.522), "quat": (0, 0, 0, 1), "scale": (1, 1, 1), "color": (.25, .25, 1), "params": (5, 5, .1)},
         {"type": 3, "pos": (-3.074, -0.087, 0.08), "quat": (0, 0, 0, 1), "scale": (1, 1, 1), "color": (1, 1, .25), "params": (.5, .5)},
     ]),
+    Case("csg7_480x270", 480, 270, prims=scenes.csg_primitives()),
+    Case("csg_random37_240x135", 240, 135, setup=_stress, prims=scenes.csg_random_primitives(37)),
+    Case("csg_random70_160x90", 160, 90, setup=_stress, prims=scenes.csg_random_primitives(70, seed=0x5EED070)),
     Case("shadow_persp_100x100", 100, 100, kind="shadow_persp", setup=_shadow_persp),
     Case("shadow_dir_256x144", 256, 144, kind="shadow_dir", setup=_shadow_dir),
 ]

@@ -72,6 +72,42 @@ def test_smin(oracle):                         # cginc:110-113
     np.testing.assert_allclose(out[:3], [math.sqrt(.5), math.sqrt(.5), 0], rtol=3e-7)
 
 
+def test_smax_closed_forms(oracle):             # cginc:120-123
+    l = oracle.lib()
+    out = f32([0, 0, 0, 0])
+
+    def w(a, b):
+        l.rmo_smax4(fp(f32([1, 0, 0, a])), fp(f32([0, 1, 0, b])), 0.5, fp(out))
+        return float(out[3])
+    assert w(0, 1) == 1.0                      # far apart: the larger operand
+    assert w(1, 0) == 1.0
+    assert w(0, 0) == -0.125                   # the reference subtracts k*h*(1-h) here too
+    # colour is a plain lerp(b.rgb, a.rgb, h): h = 1 when a is the larger
+    l.rmo_smax4(fp(f32([1, .25, .25, 5])), fp(f32([.25, 1, .25, 0])), 0.5, fp(out))
+    assert out[:3].tolist() == [1, .25, .25]
+    l.rmo_smax4(fp(f32([1, 0, 0, 1])), fp(f32([0, 1, 0, 1])), 0.5, fp(out))
+    assert out[:3].tolist() == [.5, .5, 0]
+
+
+def test_csg_ops_on_a_table_scene(oracle, default_setup):
+    """box with a negated sphere joined by smax = box minus sphere: the sphere's interior is outside"""
+    _, _, props = default_setup(16, 9)
+    box = {"type": 1, "op": 0, "pos": (0, 0, 0), "quat": (0, 0, 0, 1), "scale": (1, 1, 1), "color": (1, 1, 1), "params": (2, 2, 2)}
+    hole = {"type": 0, "op": 3, "pos": (0, 0, 0), "quat": (0, 0, 0, 1), "scale": (1, 1, 1), "color": (1, 1, 1), "params": (1,)}
+    l = oracle.lib()
+    out = f32([0, 0, 0, 0])
+    uni = oracle.Uniforms(props, prims=[box, hole])
+    l.rmo_scene(uni.ref, p3(0, 0, 0), fp(out))
+    assert out[3] == 0.5                       # centre: inside the box (-1) but 0.5 inside the carved sphere
+    l.rmo_scene(uni.ref, p3(0.9, 0.9, 0.9), fp(out))
+    assert out[3] < 0                          # box corner region, outside the sphere: solid
+    uni = oracle.Uniforms(props, prims=[box, dict(hole, op=1)])          # plain intersection
+    l.rmo_scene(uni.ref, p3(0, 0, 0), fp(out))
+    assert out[3] == -0.5
+    l.rmo_scene(uni.ref, p3(0.9, 0.9, 0.9), fp(out))
+    assert out[3] > 0
+
+
 def test_rotate_and_remap(oracle):             # cginc:62-66, 80-82
     l = oracle.lib()
     out = f32([0, 0, 0])
