@@ -98,6 +98,84 @@ def blend(c1, c2, h):                             # cginc:101-103
     return (mx * inv) * l, (my * inv) * l, (mz * inv) * l
 
 
+def euler_matrices(ax, ay, az):
+    """cginc:53-57: the three float3x3 of rotate(float3 v, float3 a), zeros and ones included"""
+    import math
+    cx, sx = f(math.cos(float(ax))), f(math.sin(float(ax)))
+    cy, sy = f(math.cos(float(ay))), f(math.sin(float(ay)))
+    cz, sz = f(math.cos(float(az))), f(math.sin(float(az)))
+    o, z = f(1), f(0)
+    mx = ((o, z, z), (z, cx, -sx), (z, sx, cx))
+    my = ((cy, z, sy), (z, o, z), (-sy, z, cy))
+    mz = ((cz, -sz, z), (sz, cz, z), (z, z, o))
+    return mx, my, mz
+
+
+def mul33v(m, x, y, z):
+    """mul(float3x3, float3): one dot product per row, every term kept"""
+    return tuple(m[r][0] * x + m[r][1] * y + m[r][2] * z for r in range(3))
+
+
+def rotate_euler(x, y, z, ms):                    # cginc:51-60: mul(mz, mul(my, mul(mx, v)))
+    mx, my, mz = ms
+    return mul33v(mz, *mul33v(my, *mul33v(mx, x, y, z)))
+
+
+def menger(x, y, z, ms):                          # cginc:295-313
+    import math
+    o = np.full_like(x, 50)
+    o2, o3 = o.copy(), o.copy()
+    for _ in range(12):
+        x, y, z = np.abs(x), np.abs(y), np.abs(z)
+        s = x < y
+        x, y = np.where(s, y, x), np.where(s, x, y)
+        s = y < z
+        y, z = np.where(s, z, y), np.where(s, y, z)
+        s = x < y
+        x, y = np.where(s, y, x), np.where(s, x, y)
+        x, y, z = rotate_euler(x, y, z, ms)
+        x, y, z = x * f(3) - f(2), y * f(3) - f(2), z * f(3) - f(2)
+        z = np.where(z < f(-1), z + f(2), z)
+        o = np.fmin(o, length3(x, y, z))
+        o2 = np.fmin(o2, length3(x, y - f(.5), z))
+        o3 = np.fmin(o3, length3(x, y, z - f(.5)))
+    return (o, o2, o3), (np.sqrt(x * x + y * y + z * z) - f(1.5)) * f(math.pow(3.0, -12.0))
+
+
+def sierpinski(x, y, z, scale, ms):               # cginc:264-293
+    import math
+    scale = f(scale)
+    x, y, z = x.copy(), y.copy(), z.copy()
+    r = x * x + y * y + z * z
+    bail = f(20)
+    o = np.full_like(x, bail)
+    o2, o3 = o.copy(), o.copy()
+    count = np.zeros(x.shape, dtype=np.int64)
+    for _ in range(15):
+        live = r < bail
+        if not live.any():
+            break
+        lx, ly, lz = x[live], y[live], z[live]
+        c = lx + ly < 0
+        lx, ly = np.where(c, -ly, lx), np.where(c, -lx, ly)
+        c = lx + lz < 0
+        lx, lz = np.where(c, -lz, lx), np.where(c, -lx, lz)
+        c = ly + lz < 0
+        ly, lz = np.where(c, -lz, ly), np.where(c, -ly, lz)
+        lx, ly, lz = rotate_euler(lx, ly, lz, ms)
+        lx = scale * lx - (scale - f(1))
+        ly = scale * ly - (scale - f(1))
+        lz = scale * lz - (scale - f(1))
+        x[live], y[live], z[live] = lx, ly, lz
+        r[live] = lx * lx + ly * ly + lz * lz
+        o[live] = np.fmin(o[live], length3(lx - f(1), ly, lz))
+        o2[live] = np.fmin(o2[live], length3(lx, ly - f(1), lz))
+        o3[live] = np.fmin(o3[live], length3(lx, ly, lz - f(1)))
+        count[live] += 1
+    pows = np.array([math.pow(float(scale), -float(i)) for i in range(16)]).astype(f)
+    return (o, o2, o3), (np.sqrt(r) - f(2)) * pows[count]
+
+
 class Scene:
     COLORS = ((1, .25, .25), (.25, 1, .25), (.25, .25, 1), (1, 1, .25))     # cginc:356-359
 
@@ -114,6 +192,13 @@ class Scene:
         for p in self.prims:
             for k in ("pos", "quat", "scale", "color", "params"):
                 p[k] = np.asarray(p[k], dtype=f)
+        # fractal bodies: wrapped like a primitive, with slot 0 of the three matrices
+        self.body = int(props.get("_RmSceneBody", 0))
+        self.slot0 = {"pos": row(props["_Positions"], 0)[:3], "quat": row(props["_Rotations"], 0),
+                      "scale": row(props["_Scales"], 0)[:3]}
+        self.fscale = props.get("_FractalScale", 2.0)
+        self.fms = euler_matrices(props.get("_FractalRotationX", 0.0), props.get("_FractalRotationY", 0.0),
+                                  props.get("_FractalRotationZ", 0.0))
 
     def prim(self, p, x, y, z):
         """cginc:336-354: rotate(p - pos, q) / scale -> primitive -> * min(scale)"""
@@ -139,6 +224,14 @@ class Scene:
         up is the left-complete tree -- a node over n leaves has the largest power of two below n
         leaves on its left.  A node is smax (cginc:120-123) when the first leaf of its right
         operand carries the SMAX bit, smin (cginc:110-113) otherwise."""
+        if self.body:
+            p0 = self.slot0
+            lx, ly, lz = rotate_q(x - p0["pos"][0], y - p0["pos"][1], z - p0["pos"][2], p0["quat"])
+            s = p0["scale"]
+            lx, ly, lz = lx / s[0], ly / s[1], lz / s[2]
+            c, d = menger(lx, ly, lz, self.fms) if self.body == 1 else sierpinski(lx, ly, lz, self.fscale, self.fms)
+            return c, d * np.fmin(s[0], np.fmin(s[1], s[2]))
+
         def node(lo, hi):
             if hi - lo == 1:
                 p = self.prims[lo]

@@ -135,6 +135,74 @@ static inline float prim_dist(const rmo_prim *pr, f3 p) {
     return (pr->op & RMO_OP_NEGATE) ? -d : d;
 }
 
+/* ---- cginc:51-60  rotate(float3 v, float3 a): euler angles, mul(mz, mul(my, mul(mx, v))) ----
+ * cos/sin of the uniform angles are taken once per frame as the double-precision libm value
+ * rounded to float.  The constant 0 and 1 entries of the three matrices are folded
+ * (1*x + 0*y + 0*z -> x), which can only change the sign of a zero result; every caller feeds
+ * the result to s*x - c, where that sign is lost. */
+typedef struct { float cx, sx, cy, sy, cz, sz; } euler_t;
+
+static euler_t euler_of(const float a[3]) {
+    euler_t e;
+    e.cx = (float)cos((double)a[0]); e.sx = (float)sin((double)a[0]);
+    e.cy = (float)cos((double)a[1]); e.sy = (float)sin((double)a[1]);
+    e.cz = (float)cos((double)a[2]); e.sz = (float)sin((double)a[2]);
+    return e;
+}
+
+static inline f3 rotate_euler(f3 v, const euler_t *e) {
+    f3 a = v3(v.x, e->cx * v.y + (-e->sx) * v.z, e->sx * v.y + e->cx * v.z);          /* mx */
+    f3 b = v3(e->cy * a.x + e->sy * a.z, a.y, (-e->sy) * a.x + e->cy * a.z);          /* my */
+    return v3(e->cz * b.x + (-e->sz) * b.y, e->sz * b.x + e->cz * b.y, b.z);          /* mz */
+}
+
+/* ---- cginc:295-313  menger(p): rgb = orbit traps, w = distance estimate -------------------- */
+static inline f4 menger(f3 p, const euler_t *rot, float pow3) {
+    float x = p.x, y = p.y, z = p.z, t;
+    float o = 50.0f, o2 = 50.0f, o3 = 50.0f;
+    for (int n = 0; n < 12; n++) {
+        x = fabsf(x); y = fabsf(y); z = fabsf(z);
+        if (x < y) { t = x; x = y; y = t; }
+        if (y < z) { t = y; y = z; z = t; }
+        if (x < y) { t = x; x = y; y = t; }
+        f3 q = rotate_euler(v3(x, y, z), rot);
+        x = q.x; y = q.y; z = q.z;
+        x = x * 3.0f - 2.0f; y = y * 3.0f - 2.0f; z = z * 3.0f - 2.0f;
+        if (z < -1.0f) z += 2.0f;
+        o  = fminf(o,  len3(v3(x, y, z)));
+        o2 = fminf(o2, len3(v3(x, y - 0.5f, z)));
+        o3 = fminf(o3, len3(v3(x, y, z - 0.5f)));
+    }
+    f4 r = {o, o2, o3, (sqrtf(x * x + y * y + z * z) - 1.5f) * pow3};       /* pow3 = pow(3.0, -12) */
+    return r;
+}
+
+/* ---- cginc:264-293  sierpinski(p) ----------------------------------------------------------
+ * pows[i] = pow(scale, -i) for the 16 values the loop counter can end on */
+static inline f4 sierpinski(f3 p, float scale, const euler_t *rot, const float pows[16]) {
+    float x = p.x, y = p.y, z = p.z;
+    float r = x * x + y * y + z * z;
+    const float bailout = 20.0f;
+    float o = bailout, o2 = bailout, o3 = bailout;
+    int i;
+    for (i = 0; i < 15 && r < bailout; i++) {
+        if (x + y < 0.0f) { float x1 = -y; y = -x; x = x1; }
+        if (x + z < 0.0f) { float x1 = -z; z = -x; x = x1; }
+        if (y + z < 0.0f) { float y1 = -z; z = -y; y = y1; }
+        f3 c = rotate_euler(v3(x, y, z), rot);
+        x = c.x; y = c.y; z = c.z;
+        x = scale * x - (scale - 1.0f);
+        y = scale * y - (scale - 1.0f);
+        z = scale * z - (scale - 1.0f);
+        r = x * x + y * y + z * z;
+        o  = fminf(o,  len3(v3(x - 1.0f, y, z)));
+        o2 = fminf(o2, len3(v3(x, y - 1.0f, z)));
+        o3 = fminf(o3, len3(v3(x, y, z - 1.0f)));
+    }
+    f4 out = {o, o2, o3, (sqrtf(r) - 2.0f) * pows[i]};
+    return out;
+}
+
 /* the reference's fixed scene as a primitive table: sphere, box, link(5,5,.1),
  * cylinder with colours (1,.25,.25) (.25,1,.25) (.25,.25,1) (1,1,.25)
  * (cginc:351-359); positions/rotations/scales from the three matrices */
@@ -160,7 +228,24 @@ typedef struct {
     rmo_prim legacy[4];
     f3 ro, light;
     f3 tl, tr, br, bl;     /* world-space corner rays */
+    int body;              /* RMO_BODY_* */
+    euler_t frot;          /* cos/sin of _FractalRotationX/Y/Z */
+    float pow3;            /* pow(3.0, -12)            (cginc:312) */
+    float pows[16];        /* pow(_FractalScale, -i)   (cginc:292) */
 } scene_ctx;
+
+/* fractal scene(): the per-primitive wrapper of cginc:336-354 with slot 0, around a fractal body */
+static inline f4 scene_fractal(const scene_ctx *c, f3 p) {
+    const rmo_prim *pr = &c->legacy[0];
+    f3 pos = v3(pr->pos[0], pr->pos[1], pr->pos[2]);
+    f4 q = {pr->quat[0], pr->quat[1], pr->quat[2], pr->quat[3]};
+    f3 s = v3(pr->scale[0], pr->scale[1], pr->scale[2]);
+    f3 pl = div3(rotate_q(sub3(p, pos), q), s);
+    f4 o = c->body == RMO_BODY_MENGER ? menger(pl, &c->frot, c->pow3)
+                                      : sierpinski(pl, c->u->fractal_scale, &c->frot, c->pows);
+    o.w = o.w * min3(s);
+    return o;
+}
 
 #define RMO_MAX_PRIMS 1024
 
@@ -169,6 +254,7 @@ typedef struct {
  * other n the same balanced pairwise tree is built level by level in index
  * order; an odd element at the end of a level is carried up unchanged. */
 static inline f4 scene(const scene_ctx *c, f3 p) {
+    if (c->body != RMO_BODY_PRIMS) return scene_fractal(c, p);
     f4 o[RMO_MAX_PRIMS];
     int first[RMO_MAX_PRIMS];          /* leftmost leaf under each node: its op bits choose the merge */
     int n = c->n;
@@ -195,6 +281,7 @@ static inline f4 scene(const scene_ctx *c, f3 p) {
 /* distance-only evaluation: exactly scene(p).w -- the .w lane of smin4 never
  * reads rgb, so dropping the colour blend changes no bit of the result */
 static inline float scene_w(const scene_ctx *c, f3 p) {
+    if (c->body != RMO_BODY_PRIMS) return scene_fractal(c, p).w;
     float o[RMO_MAX_PRIMS];
     int first[RMO_MAX_PRIMS];
     int n = c->n;
@@ -299,8 +386,13 @@ static inline f3 mul33(const float *m, f3 v) {
 
 static void scene_ctx_init(scene_ctx *c, const rmo_uniforms *u) {
     c->u = u;
+    legacy_prims(u, c->legacy);
     if (u->n_prims > 0) { c->prims = u->prims; c->n = u->n_prims; }
-    else { legacy_prims(u, c->legacy); c->prims = c->legacy; c->n = 4; }
+    else { c->prims = c->legacy; c->n = 4; }
+    c->body = u->scene_body;
+    c->frot = euler_of(u->fractal_rotation);
+    c->pow3 = (float)pow(3.0, -12.0);
+    for (int i = 0; i < 16; i++) c->pows[i] = (float)pow((double)u->fractal_scale, -(double)i);
     c->ro = v3(u->cam_pos[0], u->cam_pos[1], u->cam_pos[2]);
     c->light = v3(u->light[0], u->light[1], u->light[2]);   /* float4 -> float3 truncation */
     c->tl = mul33(u->cam_inv_view, xyz(mrow(u->frustum_corners, 0)));
@@ -508,6 +600,18 @@ void rmo_rotate_q(const float v[3], const float q[4], float out[3]) {
     out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
 float rmo_remap(float x, float o1, float o2, float n1, float n2) { return remap(x, o1, o2, n1, n2); }
+void rmo_menger(const rmo_uniforms *u, const float p[3], float out[4]) {
+    euler_t e = euler_of(u->fractal_rotation);
+    f4 r = menger(v3(p[0], p[1], p[2]), &e, (float)pow(3.0, -12.0));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+void rmo_sierpinski(const rmo_uniforms *u, const float p[3], float out[4]) {
+    euler_t e = euler_of(u->fractal_rotation);
+    float pows[16];
+    for (int i = 0; i < 16; i++) pows[i] = (float)pow((double)u->fractal_scale, -(double)i);
+    f4 r = sierpinski(v3(p[0], p[1], p[2]), u->fractal_scale, &e, pows);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
 void rmo_smax4(const float a[4], const float b[4], float k, float out[4]) {
     f4 aa = {a[0], a[1], a[2], a[3]}, bb = {b[0], b[1], b[2], b[3]};
     f4 r = smax4(aa, bb, k);

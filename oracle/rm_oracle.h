@@ -70,7 +70,16 @@ typedef struct {
     const rmo_prim *prims;       /* n_prims entries when n_prims > 0 */
     int32_t shade_miss_pixels;   /* 1: run normal+shadow on miss pixels too, as the shader does
                                     (their result is discarded by the select at shader:197-202) */
+    int32_t scene_body;          /* RMO_BODY_*: what scene() returns */
+    float fractal_scale;         /* _FractalScale (cginc:12) */
+    float fractal_rotation[3];   /* _FractalRotationX/Y/Z (cginc:13) */
 } rmo_uniforms;
+
+/* scene() bodies.  PRIMS is the reference's active code (cginc:336-363).  The fractal bodies are
+ * the functions the reference defines but only calls from a commented-out line (cginc:349); here
+ * they get the wrapper every primitive gets, with slot 0 of the three matrices:
+ *   p0 = rotate(p - _Positions[0], _Rotations[0]);  o = body(p0 / _Scales[0]);  o.w *= min(_Scales[0]) */
+enum { RMO_BODY_PRIMS = 0, RMO_BODY_MENGER = 1, RMO_BODY_SIERPINSKI = 2 };
 
 typedef struct {
     uint64_t n_pixels;
@@ -107,6 +116,8 @@ float rmo_torus(const float p[3], float tx, float ty);
 void  rmo_rotate_q(const float v[3], const float q[4], float out[3]);
 float rmo_remap(float x, float o1, float o2, float n1, float n2);
 void  rmo_smin4(const float a[4], const float b[4], float k, float out[4]);
+void  rmo_menger(const rmo_uniforms *u, const float p[3], float out[4]);
+void  rmo_sierpinski(const rmo_uniforms *u, const float p[3], float out[4]);
 void  rmo_smax4(const float a[4], const float b[4], float k, float out[4]);
 void  rmo_scene(const rmo_uniforms *u, const float p[3], float out[4]);
 void  rmo_pixel_ray(const rmo_uniforms *u, int x, int y, int w, int h, float rd[3]);

@@ -28,7 +28,8 @@ class RmoUniforms(C.Structure):
                 ("max_steps", C.c_float), ("max_dist", C.c_float), ("step_factor", C.c_float),
                 ("contact_threshold", C.c_float), ("normal_sample_scale", C.c_float), ("far_plane", C.c_float),
                 ("smooth_k", C.c_float), ("background", C.c_float * 4),
-                ("n_prims", C.c_int32), ("prims", C.POINTER(RmoPrim)), ("shade_miss_pixels", C.c_int32)]
+                ("n_prims", C.c_int32), ("prims", C.POINTER(RmoPrim)), ("shade_miss_pixels", C.c_int32),
+                ("scene_body", C.c_int32), ("fractal_scale", C.c_float), ("fractal_rotation", C.c_float * 3)]
 
 
 class RmoStats(C.Structure):
@@ -77,6 +78,9 @@ def lib() -> C.CDLL:
         l.rmo_remap.argtypes = [C.c_float] * 5
         l.rmo_smin4.restype = None
         l.rmo_smin4.argtypes = [FP, FP, C.c_float, FP]
+        for fn in (l.rmo_menger, l.rmo_sierpinski):
+            fn.restype = None
+            fn.argtypes = [C.POINTER(RmoUniforms), FP, FP]
         l.rmo_smax4.restype = None
         l.rmo_smax4.argtypes = [FP, FP, C.c_float, FP]
         l.rmo_scene.restype = None
@@ -139,6 +143,10 @@ class Uniforms:
         else:
             u.n_prims = 0
         u.shade_miss_pixels = 1 if shade_miss_pixels else 0
+        u.scene_body = int(props.get("_RmSceneBody", 0))
+        u.fractal_scale = props.get("_FractalScale", 2.0)
+        u.fractal_rotation[:] = [props.get("_FractalRotationX", 0.0), props.get("_FractalRotationY", 0.0),
+                                 props.get("_FractalRotationZ", 0.0)]
         self.u = u
 
     @property
@@ -148,7 +156,8 @@ class Uniforms:
 
 PROP_MATRICES = ("_FrustrumCorners", "_CameraInvViewMatrix", "_Positions", "_Rotations", "_Scales")
 PROP_VECTORS = ("_WorldSpaceCameraPos", "_WorldSpaceLightPos0", "_ProjectionParams", "_BackgroundColor")
-PROP_FLOATS = ("_MaxSteps", "_MaxDist", "_StepFactor", "_ContactThreshold", "_NormalSampleScale")
+PROP_FLOATS = ("_MaxSteps", "_MaxDist", "_StepFactor", "_ContactThreshold", "_NormalSampleScale",
+               "_FractalScale", "_FractalRotationX", "_FractalRotationY", "_FractalRotationZ", "_RmSceneBody")
 
 
 def props_from_material(mat) -> dict:

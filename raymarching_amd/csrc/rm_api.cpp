@@ -35,6 +35,8 @@ const char *const kDeclared[] = {
     "_WorldSpaceCameraPos", "_WorldSpaceLightPos0", "_ProjectionParams",
     // stands in for _MainTex when no source image is passed
     "_BackgroundColor",
+    // which scene() body runs: 0 primitives (cginc:336-363), 1 menger (:295-313), 2 sierpinski (:264-293)
+    "_RmSceneBody",
 };
 
 typedef std::array<float, 4> vec4;
@@ -68,8 +70,8 @@ struct rm_ctx {
     uint32_t q_epoch = 0;
     uint32_t q_last_tiles = 0, q_last_tx = 0, q_last_ty = 0; int q_last_mode = -1;
     int n_cus = 0;
-    int occ[6][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};   // resident blocks per CU by kernel variant
-    int occ_stream[6][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    int occ[7][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};   // resident blocks per CU by kernel variant (6 = fractal)
+    int occ_stream[7][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
 
     hipStream_t last_stream = nullptr;
     uint64_t last_pixels = 0;
@@ -121,6 +123,7 @@ void load_defaults(rm_ctx *c) {
     c->floats["_FractalRotationY"] = -0.26f;
     c->floats["_FractalRotationZ"] = 0.14f;
     c->floats["_FractalScale"] = 2.0f;
+    c->floats["_RmSceneBody"] = 0.0f;
     c->floats["_Glossiness"] = 0.2f;
     c->floats["_MaxDist"] = 50.0f;
     c->floats["_MaxSteps"] = 400.0f;
@@ -352,6 +355,29 @@ int build_params(rm_ctx *c, RmParams *U, hipStream_t stream) {
         U->n_prims = (int)n;
         U->lds_prims = (n <= RM_LDS_PRIMS && getf(c, "_RmLdsTable", 1.0f) != 0.0f) ? (int)n : 0;
     }
+    const int body = (int)getf(c, "_RmSceneBody", 0.0f);
+    if (body != RM_BODY_PRIMS) {
+        if (body != RM_BODY_MENGER && body != RM_BODY_SIERPINSKI) return fail(c, RM_E_ARG, "_RmSceneBody must be 0 (primitives), 1 (menger) or 2 (sierpinski)");
+        // the wrapper transform is slot 0 of the matrices, whatever table is set
+        rm_primitive lp[4];
+        legacy_prims(c, lp);
+        int pf = 0;
+        U->prims4[0] = prepare_prim(lp[0], &pf);
+        flags = pf & (RM_SF_IDENT_ROT | RM_SF_UNIT_SCALE | RM_SF_RCP);
+        U->n_prims = 0; U->lds_prims = 0;
+        U->body = body;
+        const float scale = getf(c, "_FractalScale", 2.0f);
+        U->f_scale = scale;
+        U->f_scale_m1 = scale - 1.0f;
+        const char *names[3] = {"_FractalRotationX", "_FractalRotationY", "_FractalRotationZ"};
+        for (int i = 0; i < 3; i++) {
+            const double a = (double)getf(c, names[i], 0.0f);
+            U->f_rot[2 * i] = (float)std::cos(a);
+            U->f_rot[2 * i + 1] = (float)std::sin(a);
+        }
+        U->f_pow3 = (float)std::pow(3.0, -12.0);
+        for (int i = 0; i < 16; i++) U->f_pows[i] = (float)std::pow((double)scale, -(double)i);
+    }
     U->scene_flags = flags;
     return RM_OK;
 }
@@ -455,7 +481,8 @@ int launch(rm_ctx *c, const RmParams &U, hipStream_t stream) {
     // auto: the persistent queue kernel pays on the 4-slot scene, whose frames are a mass of cheap
     // tiles plus a few long ones; N-primitive scenes are uniformly expensive per tile and run
     // faster on the plain one-block-per-tile kernel (more registers free for the table walk)
-    const int kernel = c->kernel != RM_KERNEL_AUTO ? c->kernel : (U.n_prims > 0 ? RM_KERNEL_TILE : RM_KERNEL_QUEUE);
+    int kernel = c->kernel != RM_KERNEL_AUTO ? c->kernel : (U.n_prims > 0 ? RM_KERNEL_TILE : RM_KERNEL_QUEUE);
+    if (U.body != RM_BODY_PRIMS && kernel == RM_KERNEL_STREAM) kernel = RM_KERNEL_QUEUE;      // no stream kernel for the fractal bodies
     if (kernel == RM_KERNEL_TILE) {
         unsigned n_blocks = rm_tile_blocks(U.w, U.rows, U.n_poses);
         int rc = ensure_partials(c, n_blocks, stream);

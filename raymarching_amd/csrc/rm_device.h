@@ -120,4 +120,13 @@ struct RmParams {
     uint32_t *partials;        // counter slots (per block or per wave): n_hit, primary evals, shadow evals
     RmQueue   queue;           // persistent kernel only
     RmPrimDev prims4[4];
+    // fractal scene() bodies (cginc:264-313); the wrapper transform is prims4[0]
+    int32_t  body;             // RM_BODY_*
+    float    f_scale;          // _FractalScale
+    float    f_scale_m1;       // _FractalScale - 1      (cginc:284-286)
+    float    f_rot[6];         // cos,sin of _FractalRotationX, Y, Z (cginc:53-54)
+    float    f_pow3;           // pow(3.0, -12)          (cginc:312)
+    float    f_pows[16];       // pow(_FractalScale, -i) (cginc:292)
 };
+
+enum : int32_t { RM_BODY_PRIMS = 0, RM_BODY_MENGER = 1, RM_BODY_SIERPINSKI = 2 };

@@ -658,6 +658,16 @@ __global__ RM_QLB void rm_queue_kernel4(const RmParams U) {
     rm_queue_body(U, sc);
 }
 
+// fractal scene() bodies: one kernel each, the slot-0 transform is specialised by wave-uniform branches
+__global__ RM_LB void rm_tile_kernelF(const RmParams U) {
+    SceneF sc(U);
+    rm_pixel(U, sc);
+}
+__global__ __launch_bounds__(256, RM_Q_MIN_WAVES) void rm_queue_kernelF(const RmParams U) {
+    SceneF sc(U);
+    rm_queue_body(U, sc);
+}
+
 template <bool ROT, int SCL>
 __global__ __launch_bounds__(256, RM_Q_MIN_WAVES) void rm_queue_kernelN(const RmParams U) {
     if (U.lds_prims) {
@@ -752,6 +762,17 @@ static int variant_index(const RmParams &U, bool &rot, int &scl) {
 }
 
 hipError_t rm_launch_queue(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu) {
+    if (U.body != RM_BODY_PRIMS) {
+        const size_t lds = (size_t)U.queue.bitmap_words * 4;
+        if (blocks_per_cu) {
+            int n = 0;
+            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rm_queue_kernelF, 256, lds);
+            blocks_per_cu[0] = blocks_per_cu[1] = n;
+            return e;
+        }
+        hipLaunchKernelGGL(rm_queue_kernelF, dim3(blocks), dim3(256), lds, stream, U);
+        return hipGetLastError();
+    }
     bool rot; int scl;
     variant_index(U, rot, scl);
     if (rot) {
@@ -777,12 +798,16 @@ hipError_t rm_launch_stream(const RmParams &U, unsigned blocks, hipStream_t stre
     return launch_stream_variant<false, RM_SCL_DIV>(U, blocks, stream, blocks_per_cu);
 }
 
-int rm_variant_index(const RmParams &U) { bool r; int s; return variant_index(U, r, s); }
+int rm_variant_index(const RmParams &U) { bool r; int s; return U.body != RM_BODY_PRIMS ? 6 : variant_index(U, r, s); }
 
 hipError_t rm_launch_tiles(const RmParams &U, hipStream_t stream) {
     if (U.w <= 0 || U.rows <= 0 || U.n_poses <= 0) return hipErrorInvalidValue;
     dim3 grid((unsigned)((U.w + 8 * RM_BWX - 1) / (8 * RM_BWX)), (unsigned)((U.rows + 8 * RM_BWY - 1) / (8 * RM_BWY)), (unsigned)U.n_poses);
     if (grid.y > 65535u || grid.z > 65535u) return hipErrorInvalidValue;
+    if (U.body != RM_BODY_PRIMS) {
+        hipLaunchKernelGGL(rm_tile_kernelF, grid, dim3(RM_BLOCK), 0, stream, U);
+        return hipGetLastError();
+    }
     const bool rot = !(U.scene_flags & RM_SF_IDENT_ROT);
     const int scl = (U.scene_flags & RM_SF_UNIT_SCALE) ? RM_SCL_UNIT : (U.scene_flags & RM_SF_RCP) ? RM_SCL_RCP : RM_SCL_DIV;
     if (rot) {

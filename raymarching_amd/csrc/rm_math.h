@@ -330,6 +330,105 @@ struct SceneN {
     }
 };
 
+// ---- fractal scene() bodies -------------------------------------------------------------
+// rotate(float3 v, float3 a) of cginc:51-60 with the cos/sin of the uniform angles taken on the
+// host; the constant 0/1 matrix entries are folded (a zero result may differ in sign, which the
+// following s*x - c discards).
+struct EulerV { float cx, sx, cy, sy, cz, sz; };
+RM_DI V3 rm_rotate_euler(const EulerV &e, V3 v) {
+    const float ay = e.cx * v.y - e.sx * v.z, az = e.sx * v.y + e.cx * v.z;          // mx
+    const float bx = e.cy * v.x + e.sy * az,  bz = e.cy * az - e.sy * v.x;           // my
+    return mk3(e.cz * bx - e.sz * ay, e.sz * bx + e.cz * ay, bz);                    // mz
+}
+
+// Fractal scene: body(rotate(p - pos, q) / scale) with .w scaled by min(scale), pos/q/scale from
+// slot 0 of the three matrices.  The orbit traps (rgb) are minima of lengths; sqrt is monotonic
+// and correctly rounded here, so the minimum is taken over the squared lengths and rooted once,
+// and the marches (which read only .w) skip the traps altogether.
+struct SceneF {
+    const RmParams &U;
+    PrimV P0;
+    EulerV E;
+    float three, two, scale, scale_m1;
+    bool rot, unit, rcp;
+    RM_DI explicit SceneF(const RmParams &u) : U(u) {
+        P0 = rm_prim_to_vgpr<true, RM_SCL_RCP>(u.prims4[0]);
+        E.cx = rm_vgpr(u.f_rot[0]); E.sx = rm_vgpr(u.f_rot[1]); E.cy = rm_vgpr(u.f_rot[2]);
+        E.sy = rm_vgpr(u.f_rot[3]); E.cz = rm_vgpr(u.f_rot[4]); E.sz = rm_vgpr(u.f_rot[5]);
+        three = rm_vgpr(3.0f); two = rm_vgpr(2.0f);
+        scale = rm_vgpr(u.f_scale); scale_m1 = rm_vgpr(u.f_scale_m1);
+        rot = !(u.scene_flags & RM_SF_IDENT_ROT);
+        unit = (u.scene_flags & RM_SF_UNIT_SCALE) != 0;
+        rcp = (u.scene_flags & RM_SF_RCP) != 0;
+    }
+    RM_DI V3 local(V3 p) const {                      // all three branches are wave-uniform
+        if (rot) { if (unit) return rm_to_local<true, RM_SCL_UNIT>(P0, p); if (rcp) return rm_to_local<true, RM_SCL_RCP>(P0, p); return rm_to_local<true, RM_SCL_DIV>(P0, p); }
+        if (unit) return rm_to_local<false, RM_SCL_UNIT>(P0, p);
+        if (rcp) return rm_to_local<false, RM_SCL_RCP>(P0, p);
+        return rm_to_local<false, RM_SCL_DIV>(P0, p);
+    }
+    // cginc:295-313
+    template <bool TRAPS> RM_DI V4 menger(V3 p) const {
+        float x = p.x, y = p.y, z = p.z;
+        float t0 = 2500.0f, t1 = 2500.0f, t2 = 2500.0f;          // 50^2
+#pragma nounroll
+        for (int n = 0; n < 12; n++) {
+            x = fabsf(x); y = fabsf(y); z = fabsf(z);
+            float hi = fmaxf(x, y), lo = fminf(x, y); x = hi; y = lo;      // if (x < y) swap
+            hi = fmaxf(y, z); lo = fminf(y, z); y = hi; z = lo;
+            hi = fmaxf(x, y); lo = fminf(x, y); x = hi; y = lo;
+            V3 q = rm_rotate_euler(E, mk3(x, y, z));
+            x = q.x * three - two; y = q.y * three - two; z = q.z * three - two;
+            if (z < -1.0f) z += 2.0f;
+            if (TRAPS) {
+                const float yy = y - 0.5f, zz = z - 0.5f;
+                t0 = fminf(t0, x * x + y * y + z * z);
+                t1 = fminf(t1, x * x + yy * yy + z * z);
+                t2 = fminf(t2, x * x + y * y + zz * zz);
+            }
+        }
+        V4 r;
+        r.w = (rm_sqrt(x * x + y * y + z * z) - 1.5f) * U.f_pow3;
+        if (TRAPS) { r.x = rm_sqrt(t0); r.y = rm_sqrt(t1); r.z = rm_sqrt(t2); } else { r.x = r.y = r.z = 0.0f; }
+        return r;
+    }
+    // cginc:264-293
+    template <bool TRAPS> RM_DI V4 sierpinski(V3 p) const {
+        float x = p.x, y = p.y, z = p.z;
+        float r2 = x * x + y * y + z * z;
+        float t0 = 400.0f, t1 = 400.0f, t2 = 400.0f;             // bailout^2
+        float pw = U.f_pows[0];
+        for (int i = 0; i < 15; i++) {                           // i is the same in every lane still looping
+            if (!(r2 < 20.0f)) break;
+            if (x + y < 0.0f) { const float x1 = -y; y = -x; x = x1; }
+            if (x + z < 0.0f) { const float x1 = -z; z = -x; x = x1; }
+            if (y + z < 0.0f) { const float y1 = -z; z = -y; y = y1; }
+            V3 c = rm_rotate_euler(E, mk3(x, y, z));
+            x = scale * c.x - scale_m1; y = scale * c.y - scale_m1; z = scale * c.z - scale_m1;
+            r2 = x * x + y * y + z * z;
+            pw = U.f_pows[i + 1];
+            if (TRAPS) {
+                const float xx = x - 1.0f, yy = y - 1.0f, zz = z - 1.0f;
+                t0 = fminf(t0, xx * xx + y * y + z * z);
+                t1 = fminf(t1, x * x + yy * yy + z * z);
+                t2 = fminf(t2, x * x + y * y + zz * zz);
+            }
+        }
+        V4 r;
+        r.w = (rm_sqrt(r2) - 2.0f) * pw;
+        if (TRAPS) { r.x = rm_sqrt(t0); r.y = rm_sqrt(t1); r.z = rm_sqrt(t2); } else { r.x = r.y = r.z = 0.0f; }
+        return r;
+    }
+    template <bool TRAPS> RM_DI V4 eval(V3 p) const {
+        const V3 l = local(p);
+        V4 o = U.body == RM_BODY_MENGER ? menger<TRAPS>(l) : sierpinski<TRAPS>(l);
+        if (!unit) o.w = o.w * P0.ms;
+        return o;
+    }
+    RM_DI float w(V3 p) const { return eval<false>(p).w; }
+    RM_DI V4 full(V3 p) const { return eval<true>(p); }
+};
+
 RM_DI uint32_t rm_unorm8(float x) {
     x = fminf(fmaxf(x, 0.0f), 1.0f);           // saturate; a NaN becomes 0
     return (uint32_t)floorf(x * 255.0f + 0.5f);

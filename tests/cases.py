@@ -99,6 +99,28 @@ def _fractional_steps(case, mat):
     mat.SetFloat("_NormalSampleScale", 0.001)
 
 
+def _fractal(body, closeup, scale=None, rot=None, fscale=None):
+    """a fractal scene() body around slot 0; closeup: camera 3.4 units from it instead of the default view"""
+    def f(case, mat):
+        ts = scenes.default_transforms()
+        if scale is not None:
+            ts[0].lossyScale = np.asarray(scale, dtype=F)
+        if rot is not None:
+            ts[0].rotation = rot.astype(F)
+        cam = None
+        if closeup:
+            centre = ts[0].position.astype(np.float64)
+            pos = centre + np.array([2.1, 1.3, -2.3])
+            from raymarching_amd.unity import Camera, quat_look_rotation
+            cam = Camera(transform=Transform(position=pos.astype(F), rotation=quat_look_rotation(centre - pos)),
+                         fieldOfView=60.0, aspect=case.w / case.h, nearClipPlane=0.3, farClipPlane=1000.0)
+        _base(mat, case.w, case.h, camera=cam, transforms=ts)
+        mat.SetFloat("_RmSceneBody", body)
+        if fscale is not None:
+            mat.SetFloat("_FractalScale", fscale)
+    return f
+
+
 def _shadow_persp(case, mat):
     _base(mat, case.w, case.h)
     sm = ShadowMap(scenes.shadow_camera(case.w, case.h), mat)
@@ -144,6 +166,10 @@ CASES = [
     Case("csg7_480x270", 480, 270, prims=scenes.csg_primitives()),
     Case("csg_random37_240x135", 240, 135, setup=_stress, prims=scenes.csg_random_primitives(37)),
     Case("csg_random70_160x90", 160, 90, setup=_stress, prims=scenes.csg_random_primitives(70, seed=0x5EED070)),
+    Case("menger_closeup_320x180", 320, 180, setup=_fractal(1, True)),
+    Case("menger_scaled_rotated_256x144", 256, 144, setup=_fractal(1, False, scale=(3.0, 2.5, 3.5), rot=quat_angle_axis(33.0, (1, 2, 3)))),
+    Case("sierpinski_closeup_320x180", 320, 180, setup=_fractal(2, True)),
+    Case("sierpinski_scale1p7_240x135", 240, 135, setup=_fractal(2, False, scale=(2.0, 2.0, 2.0), fscale=1.7)),
     Case("shadow_persp_100x100", 100, 100, kind="shadow_persp", setup=_shadow_persp),
     Case("shadow_dir_256x144", 256, 144, kind="shadow_dir", setup=_shadow_dir),
 ]

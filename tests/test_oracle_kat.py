@@ -108,6 +108,36 @@ def test_csg_ops_on_a_table_scene(oracle, default_setup):
     assert out[3] > 0
 
 
+def test_fractal_bodies_closed_forms(oracle, default_setup):      # cginc:264-313
+    _, _, props = default_setup(16, 9)
+    props = dict(props, _FractalRotationX=0.0, _FractalRotationY=0.0, _FractalRotationZ=0.0, _FractalScale=2.0)
+    uni = oracle.Uniforms(props)
+    l = oracle.lib()
+    out = f32([0, 0, 0, 0])
+    # sierpinski outside the bailout radius: the loop does not run, (sqrt(r) - 2) * scale^0, traps stay at 20
+    l.rmo_sierpinski(uni.ref, p3(5, 0, 0), fp(out))
+    assert out.tolist() == [20, 20, 20, 3]
+    # one fold: (1,1,1) -> 2*(1,1,1) - 1 = (1,1,1) is the fixed point of the map; after 15 rounds
+    # (sqrt(3) - 2) * 2^-15, traps = distance from (1,1,1) to the unit points = sqrt(2)
+    l.rmo_sierpinski(uni.ref, p3(1, 1, 1), fp(out))
+    s3, s2 = np.sqrt(np.float32(3)), np.sqrt(np.float32(2))
+    assert out.tolist() == [s2, s2, s2, (s3 - np.float32(2)) * np.float32(2.0 ** -15)]
+    # menger without rotation on integer points stays in exactly representable integers
+    x, y, z = 0.0, 0.0, 0.0
+    tr = [50.0, 50.0, 50.0]
+    for _ in range(12):
+        x, y, z = sorted((abs(x), abs(y), abs(z)), reverse=True)
+        x, y, z = 3 * x - 2, 3 * y - 2, 3 * z - 2
+        if z < -1:
+            z += 2
+        tr = [min(tr[0], math.sqrt(x * x + y * y + z * z)), min(tr[1], math.sqrt(x * x + (y - .5) ** 2 + z * z)),
+              min(tr[2], math.sqrt(x * x + y * y + (z - .5) ** 2))]
+    l.rmo_menger(uni.ref, p3(0, 0, 0), fp(out))
+    want_w = (np.sqrt(np.float32(x * x + y * y + z * z)) - np.float32(1.5)) * np.float32(3.0 ** -12)
+    assert out[3] == want_w
+    np.testing.assert_allclose(out[:3], tr, rtol=1e-6)
+
+
 def test_rotate_and_remap(oracle):             # cginc:62-66, 80-82
     l = oracle.lib()
     out = f32([0, 0, 0])
