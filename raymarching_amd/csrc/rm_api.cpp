@@ -481,7 +481,8 @@ int launch(rm_ctx *c, const RmParams &U, hipStream_t stream) {
     // auto: the persistent queue kernel pays on the 4-slot scene, whose frames are a mass of cheap
     // tiles plus a few long ones; N-primitive scenes are uniformly expensive per tile and run
     // faster on the plain one-block-per-tile kernel (more registers free for the table walk)
-    int kernel = c->kernel != RM_KERNEL_AUTO ? c->kernel : (U.n_prims > 0 ? RM_KERNEL_TILE : RM_KERNEL_QUEUE);
+    // (the fractal bodies are uniformly expensive too: measured 1.18 ms tile vs 1.57 ms queue at 1080p)
+    int kernel = c->kernel != RM_KERNEL_AUTO ? c->kernel : ((U.n_prims > 0 || U.body != RM_BODY_PRIMS) ? RM_KERNEL_TILE : RM_KERNEL_QUEUE);
     if (U.body != RM_BODY_PRIMS && kernel == RM_KERNEL_STREAM) kernel = RM_KERNEL_QUEUE;      // no stream kernel for the fractal bodies
     if (kernel == RM_KERNEL_TILE) {
         unsigned n_blocks = rm_tile_blocks(U.w, U.rows, U.n_poses);

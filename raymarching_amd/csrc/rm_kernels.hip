@@ -663,7 +663,7 @@ __global__ RM_LB void rm_tile_kernelF(const RmParams U) {
     SceneF sc(U);
     rm_pixel(U, sc);
 }
-__global__ __launch_bounds__(256, RM_Q_MIN_WAVES) void rm_queue_kernelF(const RmParams U) {
+__global__ __launch_bounds__(256, RM_Q_MIN_WAVES_ROT) void rm_queue_kernelF(const RmParams U) {
     SceneF sc(U);
     rm_queue_body(U, sc);
 }

@@ -121,6 +121,17 @@ def _fractal(body, closeup, scale=None, rot=None, fscale=None):
     return f
 
 
+def _edge(floats=None, vectors=None):
+    """default scene with degenerate uniforms"""
+    def f(case, mat):
+        _base(mat, case.w, case.h)
+        for k, v in (floats or {}).items():
+            mat.SetFloat(k, v)
+        for k, v in (vectors or {}).items():
+            mat.SetVector(k, np.asarray(v, dtype=F))
+    return f
+
+
 def _shadow_persp(case, mat):
     _base(mat, case.w, case.h)
     sm = ShadowMap(scenes.shadow_camera(case.w, case.h), mat)
@@ -170,6 +181,23 @@ CASES = [
     Case("menger_scaled_rotated_256x144", 256, 144, setup=_fractal(1, False, scale=(3.0, 2.5, 3.5), rot=quat_angle_axis(33.0, (1, 2, 3)))),
     Case("sierpinski_closeup_320x180", 320, 180, setup=_fractal(2, True)),
     Case("sierpinski_scale1p7_240x135", 240, 135, setup=_fractal(2, False, scale=(2.0, 2.0, 2.0), fscale=1.7)),
+    # degenerate uniforms: the loops must stop (or not start) exactly where the shader's would
+    Case("edge_zero_steps_64x36", 64, 36, setup=_edge({"_MaxSteps": 0.0})),
+    Case("edge_negative_steps_64x36", 64, 36, setup=_edge({"_MaxSteps": -3.0})),
+    Case("edge_one_step_64x36", 64, 36, setup=_edge({"_MaxSteps": 1.0})),
+    Case("edge_zero_dist_64x36", 64, 36, setup=_edge({"_MaxDist": 0.0})),
+    Case("edge_zero_stepfactor_64x36", 64, 36, setup=_edge({"_StepFactor": 0.0, "_MaxSteps": 50.0})),
+    Case("edge_negative_stepfactor_64x36", 64, 36, setup=_edge({"_StepFactor": -0.7, "_MaxSteps": 50.0})),
+    Case("edge_zero_normal_scale_128x72", 128, 72, setup=_edge({"_NormalSampleScale": 0.0})),
+    Case("edge_negative_normal_scale_128x72", 128, 72, setup=_edge({"_NormalSampleScale": -1.0})),
+    Case("edge_zero_light_128x72", 128, 72, setup=_edge(vectors={"_WorldSpaceLightPos0": (0, 0, 0, 0)})),
+    Case("edge_light_from_below_128x72", 128, 72, setup=_edge(vectors={"_WorldSpaceLightPos0": (0.3, -0.8, 0.2, 0)})),
+    Case("edge_camera_inside_box_128x72", 128, 72, setup=_edge(vectors={"_WorldSpaceCameraPos": (-0.74, 0.929, 0.0, 0)})),
+    Case("edge_big_steps_2000_cap_96x54", 96, 54, setup=_edge({"_MaxSteps": 5000.0, "_StepFactor": 0.01, "_MaxDist": 30.0})),
+    Case("edge_nan_camera_32x18", 32, 18, setup=_edge({"_MaxSteps": 20.0}, vectors={"_WorldSpaceCameraPos": (float("nan"), 1, -11, 0)})),
+    Case("edge_inf_camera_32x18", 32, 18, setup=_edge({"_MaxSteps": 20.0}, vectors={"_WorldSpaceCameraPos": (float("inf"), 1, -11, 0)})),
+    Case("tall_3x257", 3, 257),
+    Case("wide_1025x2", 1025, 2),
     Case("shadow_persp_100x100", 100, 100, kind="shadow_persp", setup=_shadow_persp),
     Case("shadow_dir_256x144", 256, 144, kind="shadow_dir", setup=_shadow_dir),
 ]
