@@ -98,6 +98,190 @@ def blend(c1, c2, h):                             # cginc:101-103
     return (mx * inv) * l, (my * inv) * l, (mz * inv) * l
 
 
+# ---- canonical transcendental functions: float -> float through IEEE double arithmetic in a fixed
+# operation order (the definition is stated with the C oracle); float64 ufuncs round once per operation
+d = np.float64
+PIO2_HI, PIO2_LO = 1.57079632673412561417e+00, 6.07710050650619224932e-11
+PI, PIO2, PIO4 = 3.14159265358979311600e+00, 1.57079632679489655800e+00, 7.85398163397448278999e-01
+LN2, LN2_HI, LN2_LO = 6.93147180559945286227e-01, 6.93147180369123816490e-01, 1.90821492927058770002e-10
+FACT = [1.0]
+for _n in range(1, 18):
+    FACT.append(FACT[-1] * _n)
+
+
+def _sin_poly(r):
+    q = r * r
+    p = np.full_like(r, 1.0 / FACT[17])
+    for n, sign in ((15, -1), (13, 1), (11, -1), (9, 1), (7, -1), (5, 1), (3, -1)):
+        p = p * q + sign * (1.0 / FACT[n])
+    return r + r * (q * p)
+
+
+def _cos_poly(r):
+    q = r * r
+    p = np.full_like(r, 1.0 / FACT[16])
+    for n, sign in ((14, -1), (12, 1), (10, -1), (8, 1), (6, -1), (4, 1)):
+        p = p * q + sign * (1.0 / FACT[n])
+    p = p * q - 0.5
+    return 1.0 + q * p
+
+
+def _reduce(x):
+    k = np.floor(x * (1.0 / PIO2) + 0.5)
+    r = (x - k * PIO2_HI) - k * PIO2_LO
+    n = (k - 4.0 * np.floor(k * 0.25))
+    with np.errstate(invalid="ignore"):
+        n = np.where(np.isfinite(n), n, 0).astype(np.int64)
+    return r, n
+
+
+def c_sin(xf):
+    r, n = _reduce(xf.astype(d))
+    v = np.where(n & 1, _cos_poly(r), _sin_poly(r))
+    return np.where(n & 2, -v, v).astype(f)
+
+
+def c_cos(xf):
+    r, n = _reduce(xf.astype(d))
+    v = np.where(n & 1, _sin_poly(r), _cos_poly(r))
+    return np.where((n + 1) & 2, -v, v).astype(f)
+
+
+def _atan01(t):
+    big = t > 0.41421356237309503
+    u = np.where(big, (t - 1.0) / (t + 1.0), t)
+    base = np.where(big, PIO4, 0.0)
+    q = u * u
+    p = np.full_like(t, 1.0 / 43.0)
+    for n in range(41, 0, -2):
+        p = 1.0 / float(n) - q * p
+    return base + u * p
+
+
+def _atan2d(y, x):
+    ay, ax = np.abs(y), np.abs(x)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        a = np.where(ay > ax, PIO2 - _atan01(ax / ay), np.where(ax > 0.0, _atan01(ay / ax), ay / ax))
+    a = np.where(x < 0.0, PI - a, a)
+    return np.where(y < 0.0, -a, a)
+
+
+def c_atan2(yf, xf):
+    return _atan2d(yf.astype(d), xf.astype(d)).astype(f)
+
+
+def _one_minus_sq(v):
+    t = 1.0 - v * v
+    return np.where(t > 0.0, t, 0.0)
+
+
+def c_acos(vf):
+    v = vf.astype(d)
+    return _atan2d(np.sqrt(_one_minus_sq(v)), v).astype(f)
+
+
+def c_asin(vf):
+    v = vf.astype(d)
+    return _atan2d(v, np.sqrt(_one_minus_sq(v))).astype(f)
+
+
+def _logd(x):
+    m, e = np.frexp(x)
+    m = m * 2.0
+    e = e - 1
+    big = m > 1.4142135623730951
+    m = np.where(big, m * 0.5, m)
+    e = np.where(big, e + 1, e)
+    s = (m - 1.0) / (m + 1.0)
+    q = s * s
+    p = np.full_like(x, 1.0 / 25.0)
+    for n in range(23, 0, -2):
+        p = 1.0 / float(n) + q * p
+    return e.astype(d) * LN2 + 2.0 * s * p
+
+
+def _expd(y):
+    ok = (y < 700.0) & (y >= -700.0)
+    yy = np.where(ok, y, 0.0)
+    k = np.floor(yy * (1.0 / LN2) + 0.5)
+    fr = (yy - k * LN2_HI) - k * LN2_LO
+    p = np.full_like(y, 1.0 / FACT[14])
+    for n in range(13, -1, -1):
+        p = 1.0 / FACT[n] + fr * p
+    out = np.ldexp(p, k.astype(np.int64))
+    over = np.where(y > 0.0, np.inf, y)                   # overflow; NaN stays NaN
+    return np.where(ok, out, np.where(y < -700.0, 0.0, over))
+
+
+def c_log(xf):
+    x = xf.astype(d)
+    pos = (xf > 0) & np.isfinite(xf)
+    with np.errstate(all="ignore"):
+        v = _logd(np.where(pos, x, 1.0)).astype(f)
+    special = np.where(xf == 0, f(-np.inf), np.where(np.isposinf(xf), f(np.inf), f(np.nan)))
+    return np.where(pos, v, special).astype(f)
+
+
+def c_pow(xf, e):
+    """x >= 0 (a length), e a scalar float32"""
+    e = f(e)
+    pos = (xf > 0) & np.isfinite(xf)
+    with np.errstate(all="ignore"):
+        v = _expd(d(e) * _logd(np.where(pos, xf.astype(d), 1.0))).astype(f)
+    at0 = f(0) if e > 0 else (f(1) if e == 0 else f(np.inf))
+    atinf = f(np.inf) if e > 0 else (f(1) if e == 0 else f(0))
+    special = np.where(xf == 0, at0, np.where(np.isposinf(xf), atinf, f(np.nan)))
+    return np.where(pos, v, special).astype(f)
+
+
+def _bulb(x, y, z, e, brot):
+    """cginc:194-227 (mandelbulb, brot False) and cginc:229-262 (mandelbrot, brot True)"""
+    e = f(e)
+    px, py, pz = x, y, z
+    zx, zy, zz = x.copy(), y.copy(), z.copy()
+    dr = np.ones_like(x)
+    r = np.zeros_like(x)
+    o = np.full_like(x, 10)
+    o2, o3 = o.copy(), o.copy()
+    live = np.ones(x.shape, dtype=bool)
+    for _ in range(12):
+        idx = np.nonzero(live)[0]
+        if idx.size == 0:
+            break
+        ax, ay, az = zx[idx], zy[idx], zz[idx]
+        rr = length3(ax, ay, az)
+        r[idx] = rr
+        o[idx] = np.fmin(o[idx], length3(ax, ay, az))
+        if brot:
+            o2[idx] = np.fmin(o2[idx], length3(ax - f(1), ay, az))
+            o3[idx] = np.fmin(o3[idx], length3(ax - f(2), ay, az))
+        else:
+            o2[idx] = np.fmin(o2[idx], length3(ax, ay, az - f(1)))
+            o3[idx] = np.fmin(o3[idx], length3(ax, ay, az - f(2)))
+        go = ~(rr > f(10))
+        live[idx[~go]] = False
+        idx, ax, ay, az, rr = idx[go], ax[go], ay[go], az[go], rr[go]
+        if idx.size == 0:
+            break
+        with np.errstate(all="ignore"):
+            ratio = az / rr
+        if brot:
+            theta, phi = c_atan2(ay, ax), c_asin(ratio)
+        else:
+            theta, phi = c_acos(ratio), c_atan2(ay, ax)
+        dr[idx] = c_pow(rr, e - f(1)) * e * dr[idx] + f(1)
+        zr = c_pow(rr, e)
+        theta, phi = theta * e, phi * e
+        if brot:
+            nx, ny, nz = zr * (c_cos(theta) * c_cos(phi)), zr * (c_sin(theta) * c_cos(phi)), zr * (-c_sin(phi))
+        else:
+            nx, ny, nz = zr * (c_sin(theta) * c_cos(phi)), zr * (c_sin(phi) * c_sin(theta)), zr * c_cos(theta)
+        zx[idx], zy[idx], zz[idx] = nx + px[idx], ny + py[idx], nz + pz[idx]
+    with np.errstate(all="ignore"):
+        w = f(.5) * c_log(r) * r / dr
+    return (o, o2, o3), w
+
+
 def euler_matrices(ax, ay, az):
     """cginc:53-57: the three float3x3 of rotate(float3 v, float3 a), zeros and ones included"""
     import math
@@ -197,6 +381,9 @@ class Scene:
         self.slot0 = {"pos": row(props["_Positions"], 0)[:3], "quat": row(props["_Rotations"], 0),
                       "scale": row(props["_Scales"], 0)[:3]}
         self.fscale = props.get("_FractalScale", 2.0)
+        self.fpower = props.get("_RmFractalPower", 0.0)
+        if not self.fpower > 0:
+            self.fpower = 7.0 if self.body == 3 else 2.0
         self.fms = euler_matrices(props.get("_FractalRotationX", 0.0), props.get("_FractalRotationY", 0.0),
                                   props.get("_FractalRotationZ", 0.0))
 
@@ -229,8 +416,13 @@ class Scene:
             lx, ly, lz = rotate_q(x - p0["pos"][0], y - p0["pos"][1], z - p0["pos"][2], p0["quat"])
             s = p0["scale"]
             lx, ly, lz = lx / s[0], ly / s[1], lz / s[2]
-            c, d = menger(lx, ly, lz, self.fms) if self.body == 1 else sierpinski(lx, ly, lz, self.fscale, self.fms)
-            return c, d * np.fmin(s[0], np.fmin(s[1], s[2]))
+            if self.body == 1:
+                c, dist = menger(lx, ly, lz, self.fms)
+            elif self.body == 2:
+                c, dist = sierpinski(lx, ly, lz, self.fscale, self.fms)
+            else:
+                c, dist = _bulb(lx, ly, lz, self.fpower, self.body == 4)
+            return c, dist * np.fmin(s[0], np.fmin(s[1], s[2]))
 
         def node(lo, hi):
             if hi - lo == 1:

@@ -156,6 +156,183 @@ static inline f3 rotate_euler(f3 v, const euler_t *e) {
     return v3(e->cz * b.x + (-e->sz) * b.y, e->sz * b.x + e->cz * b.y, b.z);          /* mz */
 }
 
+/* ---- canonical transcendental functions ----------------------------------------------
+ * HLSL leaves sin/cos/acos/asin/atan2/pow/log precision to the driver, so the fractal bodies that
+ * use them (cginc:194-262) have no bit-defined result in the reference.  They are fixed here as
+ * float -> float functions evaluated in IEEE double with +,-,*,/ and sqrt only (no library call,
+ * no fused multiply-add), in the operation order written below; the double result is rounded to
+ * float once.  Any IEEE machine computes the same bits, and each result is within 1 float ulp of
+ * the true function (tests/test_oracle_kat.py checks them against libm). */
+static const double RM_PIO2_HI = 1.57079632673412561417e+00;   /* first 33 bits of pi/2 */
+static const double RM_PIO2_LO = 6.07710050650619224932e-11;   /* pi/2 - RM_PIO2_HI */
+static const double RM_PI      = 3.14159265358979311600e+00;
+static const double RM_PIO2    = 1.57079632679489655800e+00;
+static const double RM_PIO4    = 7.85398163397448278999e-01;
+static const double RM_LN2     = 6.93147180559945286227e-01;
+static const double RM_LN2_HI  = 6.93147180369123816490e-01;   /* first 32 bits of ln 2 */
+static const double RM_LN2_LO  = 1.90821492927058770002e-10;   /* ln 2 - RM_LN2_HI */
+
+/* r in [-pi/4, pi/4]: Taylor series of sin and cos in Horner form on r*r */
+static inline double c_sin_poly(double r) {
+    double q = r * r;
+    double p = 1.0 / 355687428096000.0;                  /*  1/17! */
+    p = p * q - 1.0 / 1307674368000.0;                   /* -1/15! */
+    p = p * q + 1.0 / 6227020800.0;                      /*  1/13! */
+    p = p * q - 1.0 / 39916800.0;                        /* -1/11! */
+    p = p * q + 1.0 / 362880.0;                          /*  1/9!  */
+    p = p * q - 1.0 / 5040.0;                            /* -1/7!  */
+    p = p * q + 1.0 / 120.0;                             /*  1/5!  */
+    p = p * q - 1.0 / 6.0;                               /* -1/3!  */
+    return r + r * (q * p);
+}
+static inline double c_cos_poly(double r) {
+    double q = r * r;
+    double p = 1.0 / 20922789888000.0;                   /*  1/16! */
+    p = p * q - 1.0 / 87178291200.0;                     /* -1/14! */
+    p = p * q + 1.0 / 479001600.0;                       /*  1/12! */
+    p = p * q - 1.0 / 3628800.0;                         /* -1/10! */
+    p = p * q + 1.0 / 40320.0;                           /*  1/8!  */
+    p = p * q - 1.0 / 720.0;                             /* -1/6!  */
+    p = p * q + 1.0 / 24.0;                              /*  1/4!  */
+    p = p * q - 0.5;                                     /* -1/2!  */
+    return 1.0 + q * p;
+}
+/* quadrant k and reduced argument: x = k*pi/2 + r */
+static inline double c_reduce(double x, int *quadrant) {
+    double k = floor(x * (1.0 / RM_PIO2) + 0.5);
+    double r = (x - k * RM_PIO2_HI) - k * RM_PIO2_LO;
+    double k4 = k - 4.0 * floor(k * 0.25);
+    *quadrant = (int)k4;
+    return r;
+}
+static inline float c_sin(float xf) {
+    int n;
+    double r = c_reduce((double)xf, &n);
+    double v = (n & 1) ? c_cos_poly(r) : c_sin_poly(r);
+    return (float)((n & 2) ? -v : v);
+}
+static inline float c_cos(float xf) {
+    int n;
+    double r = c_reduce((double)xf, &n);
+    double v = (n & 1) ? c_sin_poly(r) : c_cos_poly(r);
+    return (float)(((n + 1) & 2) ? -v : v);
+}
+/* atan of t in [0, 1] */
+static inline double c_atan01(double t) {
+    double base = 0.0, u = t;
+    if (t > 0.41421356237309503) { u = (t - 1.0) / (t + 1.0); base = RM_PIO4; }      /* tan(pi/8) */
+    double q = u * u;
+    double p = 1.0 / 43.0;
+    for (int n = 41; n >= 1; n -= 2) p = 1.0 / (double)n - q * p;                     /* 1 - q/3 + q^2/5 - ... */
+    return base + u * p;
+}
+static inline double c_atan2d(double y, double x) {
+    double ay = fabs(y), ax = fabs(x);
+    double a;
+    if (ay > ax) a = RM_PIO2 - c_atan01(ax / ay);
+    else if (ax > 0.0) a = c_atan01(ay / ax);
+    else a = ay / ax;                       /* 0/0 (and any NaN) stays NaN: atan2(0,0) is undefined in HLSL */
+    if (x < 0.0) a = RM_PI - a;
+    return (y < 0.0) ? -a : a;
+}
+static inline float c_atan2(float y, float x) { return (float)c_atan2d((double)y, (double)x); }
+static inline float c_acos(float vf) {
+    double v = (double)vf, t = 1.0 - v * v;
+    if (!(t > 0.0)) t = 0.0;
+    return (float)c_atan2d(sqrt(t), v);
+}
+static inline float c_asin(float vf) {
+    double v = (double)vf, t = 1.0 - v * v;
+    if (!(t > 0.0)) t = 0.0;
+    return (float)c_atan2d(v, sqrt(t));
+}
+/* natural log of a finite x > 0 */
+static inline double c_logd(double x) {
+    int e;
+    double m = frexp(x, &e) * 2.0;          /* m in [1, 2), x = m * 2^(e-1) */
+    e -= 1;
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    double s = (m - 1.0) / (m + 1.0), q = s * s;
+    double p = 1.0 / 25.0;
+    for (int n = 23; n >= 1; n -= 2) p = 1.0 / (double)n + q * p;                     /* 1 + q/3 + q^2/5 + ... */
+    return (double)e * RM_LN2 + 2.0 * s * p;
+}
+static inline double c_expd(double y) {
+    if (!(y < 700.0)) return y > 0.0 ? INFINITY : y;        /* overflow; NaN stays NaN */
+    if (y < -700.0) return 0.0;
+    double k = floor(y * (1.0 / RM_LN2) + 0.5);
+    double f = (y - k * RM_LN2_HI) - k * RM_LN2_LO;
+    double p = 1.0 / 87178291200.0;                                                   /* 1/14! */
+    static const double inv_fact[14] = {1.0, 1.0, 1.0 / 2.0, 1.0 / 6.0, 1.0 / 24.0, 1.0 / 120.0, 1.0 / 720.0, 1.0 / 5040.0,
+                                        1.0 / 40320.0, 1.0 / 362880.0, 1.0 / 3628800.0, 1.0 / 39916800.0,
+                                        1.0 / 479001600.0, 1.0 / 6227020800.0};
+    for (int n = 13; n >= 0; n--) p = inv_fact[n] + f * p;
+    return ldexp(p, (int)k);
+}
+static inline float c_log(float xf) {
+    if (!(xf > 0.0f)) return xf == 0.0f ? -INFINITY : NAN;
+    if (isinf(xf)) return xf;
+    return (float)c_logd((double)xf);
+}
+static inline float c_pow(float xf, float ef) {             /* x >= 0 only (a length) */
+    if (!(xf > 0.0f)) {
+        if (xf == 0.0f) return ef > 0.0f ? 0.0f : (ef == 0.0f ? 1.0f : INFINITY);
+        return NAN;
+    }
+    if (isinf(xf)) return ef > 0.0f ? xf : (ef == 0.0f ? 1.0f : 0.0f);
+    return (float)c_expd((double)ef * c_logd((double)xf));
+}
+
+/* ---- cginc:194-227  mandelbulb(p, e, iters=12, bailout=10) ---------------------------------- */
+static inline f4 mandelbulb(f3 p, float e) {
+    f3 z = p;
+    float dr = 1.0f, r = 0.0f;
+    const float bailout = 10.0f;
+    float o = bailout, o2 = bailout, o3 = bailout;
+    for (int i = 0; i < 12; i++) {
+        r = len3(z);
+        o  = fminf(o,  len3(v3(z.x, z.y, z.z)));
+        o2 = fminf(o2, len3(v3(z.x, z.y, z.z - 1.0f)));
+        o3 = fminf(o3, len3(v3(z.x, z.y, z.z - 2.0f)));
+        if (r > bailout) break;
+        float theta = c_acos(z.z / r);
+        float phi = c_atan2(z.y, z.x);
+        dr = c_pow(r, e - 1.0f) * e * dr + 1.0f;
+        float zr = c_pow(r, e);
+        theta = theta * e;
+        phi = phi * e;
+        z = v3(zr * (c_sin(theta) * c_cos(phi)), zr * (c_sin(phi) * c_sin(theta)), zr * c_cos(theta));
+        z = add3(z, p);
+    }
+    f4 out = {o, o2, o3, 0.5f * c_log(r) * r / dr};
+    return out;
+}
+
+/* ---- cginc:229-262  mandelbrot(p, e, iters=12, bailout=10) ---------------------------------- */
+static inline f4 mandelbrot3(f3 p, float e) {
+    f3 z = p;
+    float dr = 1.0f, r = 0.0f;
+    const float bailout = 10.0f;
+    float o = bailout, o2 = bailout, o3 = bailout;
+    for (int i = 0; i < 12; i++) {
+        o  = fminf(o,  len3(v3(z.x, z.y, z.z)));
+        o2 = fminf(o2, len3(v3(z.x - 1.0f, z.y, z.z)));
+        o3 = fminf(o3, len3(v3(z.x - 2.0f, z.y, z.z)));
+        r = len3(z);
+        if (r > bailout) break;
+        float theta = c_atan2(z.y, z.x);
+        float phi = c_asin(z.z / r);
+        dr = c_pow(r, e - 1.0f) * e * dr + 1.0f;
+        float zr = c_pow(r, e);
+        theta = theta * e;
+        phi = phi * e;
+        z = v3(zr * (c_cos(theta) * c_cos(phi)), zr * (c_sin(theta) * c_cos(phi)), zr * (-c_sin(phi)));
+        z = add3(z, p);
+    }
+    f4 out = {o, o2, o3, 0.5f * c_log(r) * r / dr};
+    return out;
+}
+
 /* ---- cginc:295-313  menger(p): rgb = orbit traps, w = distance estimate -------------------- */
 static inline f4 menger(f3 p, const euler_t *rot, float pow3) {
     float x = p.x, y = p.y, z = p.z, t;
@@ -232,6 +409,7 @@ typedef struct {
     euler_t frot;          /* cos/sin of _FractalRotationX/Y/Z */
     float pow3;            /* pow(3.0, -12)            (cginc:312) */
     float pows[16];        /* pow(_FractalScale, -i)   (cginc:292) */
+    float fpower;          /* e of mandelbulb (default 7, cginc:194) / mandelbrot (default 2, cginc:229) */
 } scene_ctx;
 
 /* fractal scene(): the per-primitive wrapper of cginc:336-354 with slot 0, around a fractal body */
@@ -241,8 +419,13 @@ static inline f4 scene_fractal(const scene_ctx *c, f3 p) {
     f4 q = {pr->quat[0], pr->quat[1], pr->quat[2], pr->quat[3]};
     f3 s = v3(pr->scale[0], pr->scale[1], pr->scale[2]);
     f3 pl = div3(rotate_q(sub3(p, pos), q), s);
-    f4 o = c->body == RMO_BODY_MENGER ? menger(pl, &c->frot, c->pow3)
-                                      : sierpinski(pl, c->u->fractal_scale, &c->frot, c->pows);
+    f4 o;
+    switch (c->body) {
+    case RMO_BODY_MENGER:     o = menger(pl, &c->frot, c->pow3); break;
+    case RMO_BODY_SIERPINSKI: o = sierpinski(pl, c->u->fractal_scale, &c->frot, c->pows); break;
+    case RMO_BODY_MANDELBULB: o = mandelbulb(pl, c->fpower); break;
+    default:                  o = mandelbrot3(pl, c->fpower); break;
+    }
     o.w = o.w * min3(s);
     return o;
 }
@@ -392,6 +575,7 @@ static void scene_ctx_init(scene_ctx *c, const rmo_uniforms *u) {
     c->body = u->scene_body;
     c->frot = euler_of(u->fractal_rotation);
     c->pow3 = (float)pow(3.0, -12.0);
+    c->fpower = u->fractal_power > 0.0f ? u->fractal_power : (u->scene_body == RMO_BODY_MANDELBULB ? 7.0f : 2.0f);
     for (int i = 0; i < 16; i++) c->pows[i] = (float)pow((double)u->fractal_scale, -(double)i);
     c->ro = v3(u->cam_pos[0], u->cam_pos[1], u->cam_pos[2]);
     c->light = v3(u->light[0], u->light[1], u->light[2]);   /* float4 -> float3 truncation */
@@ -600,6 +784,21 @@ void rmo_rotate_q(const float v[3], const float q[4], float out[3]) {
     out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
 float rmo_remap(float x, float o1, float o2, float n1, float n2) { return remap(x, o1, o2, n1, n2); }
+float rmo_c_sin(float x) { return c_sin(x); }
+float rmo_c_cos(float x) { return c_cos(x); }
+float rmo_c_acos(float x) { return c_acos(x); }
+float rmo_c_asin(float x) { return c_asin(x); }
+float rmo_c_atan2(float y, float x) { return c_atan2(y, x); }
+float rmo_c_log(float x) { return c_log(x); }
+float rmo_c_pow(float x, float e) { return c_pow(x, e); }
+void rmo_mandelbulb(const float p[3], float e, float out[4]) {
+    f4 r = mandelbulb(v3(p[0], p[1], p[2]), e);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+void rmo_mandelbrot(const float p[3], float e, float out[4]) {
+    f4 r = mandelbrot3(v3(p[0], p[1], p[2]), e);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
 void rmo_menger(const rmo_uniforms *u, const float p[3], float out[4]) {
     euler_t e = euler_of(u->fractal_rotation);
     f4 r = menger(v3(p[0], p[1], p[2]), &e, (float)pow(3.0, -12.0));

@@ -73,13 +73,14 @@ typedef struct {
     int32_t scene_body;          /* RMO_BODY_*: what scene() returns */
     float fractal_scale;         /* _FractalScale (cginc:12) */
     float fractal_rotation[3];   /* _FractalRotationX/Y/Z (cginc:13) */
+    float fractal_power;         /* e of mandelbulb/mandelbrot; <= 0: the function's default (7 / 2) */
 } rmo_uniforms;
 
 /* scene() bodies.  PRIMS is the reference's active code (cginc:336-363).  The fractal bodies are
  * the functions the reference defines but only calls from a commented-out line (cginc:349); here
  * they get the wrapper every primitive gets, with slot 0 of the three matrices:
  *   p0 = rotate(p - _Positions[0], _Rotations[0]);  o = body(p0 / _Scales[0]);  o.w *= min(_Scales[0]) */
-enum { RMO_BODY_PRIMS = 0, RMO_BODY_MENGER = 1, RMO_BODY_SIERPINSKI = 2 };
+enum { RMO_BODY_PRIMS = 0, RMO_BODY_MENGER = 1, RMO_BODY_SIERPINSKI = 2, RMO_BODY_MANDELBULB = 3, RMO_BODY_MANDELBROT = 4 };
 
 typedef struct {
     uint64_t n_pixels;
@@ -116,6 +117,15 @@ float rmo_torus(const float p[3], float tx, float ty);
 void  rmo_rotate_q(const float v[3], const float q[4], float out[3]);
 float rmo_remap(float x, float o1, float o2, float n1, float n2);
 void  rmo_smin4(const float a[4], const float b[4], float k, float out[4]);
+float rmo_c_sin(float x);
+float rmo_c_cos(float x);
+float rmo_c_acos(float x);
+float rmo_c_asin(float x);
+float rmo_c_atan2(float y, float x);
+float rmo_c_log(float x);
+float rmo_c_pow(float x, float e);
+void  rmo_mandelbulb(const float p[3], float e, float out[4]);
+void  rmo_mandelbrot(const float p[3], float e, float out[4]);
 void  rmo_menger(const rmo_uniforms *u, const float p[3], float out[4]);
 void  rmo_sierpinski(const rmo_uniforms *u, const float p[3], float out[4]);
 void  rmo_smax4(const float a[4], const float b[4], float k, float out[4]);

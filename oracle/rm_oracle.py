@@ -29,7 +29,8 @@ class RmoUniforms(C.Structure):
                 ("contact_threshold", C.c_float), ("normal_sample_scale", C.c_float), ("far_plane", C.c_float),
                 ("smooth_k", C.c_float), ("background", C.c_float * 4),
                 ("n_prims", C.c_int32), ("prims", C.POINTER(RmoPrim)), ("shade_miss_pixels", C.c_int32),
-                ("scene_body", C.c_int32), ("fractal_scale", C.c_float), ("fractal_rotation", C.c_float * 3)]
+                ("scene_body", C.c_int32), ("fractal_scale", C.c_float), ("fractal_rotation", C.c_float * 3),
+                ("fractal_power", C.c_float)]
 
 
 class RmoStats(C.Structure):
@@ -78,6 +79,15 @@ def lib() -> C.CDLL:
         l.rmo_remap.argtypes = [C.c_float] * 5
         l.rmo_smin4.restype = None
         l.rmo_smin4.argtypes = [FP, FP, C.c_float, FP]
+        for fn in (l.rmo_c_sin, l.rmo_c_cos, l.rmo_c_acos, l.rmo_c_asin, l.rmo_c_log):
+            fn.restype = C.c_float
+            fn.argtypes = [C.c_float]
+        for fn in (l.rmo_c_atan2, l.rmo_c_pow):
+            fn.restype = C.c_float
+            fn.argtypes = [C.c_float, C.c_float]
+        for fn in (l.rmo_mandelbulb, l.rmo_mandelbrot):
+            fn.restype = None
+            fn.argtypes = [FP, C.c_float, FP]
         for fn in (l.rmo_menger, l.rmo_sierpinski):
             fn.restype = None
             fn.argtypes = [C.POINTER(RmoUniforms), FP, FP]
@@ -145,6 +155,7 @@ class Uniforms:
         u.shade_miss_pixels = 1 if shade_miss_pixels else 0
         u.scene_body = int(props.get("_RmSceneBody", 0))
         u.fractal_scale = props.get("_FractalScale", 2.0)
+        u.fractal_power = props.get("_RmFractalPower", 0.0)
         u.fractal_rotation[:] = [props.get("_FractalRotationX", 0.0), props.get("_FractalRotationY", 0.0),
                                  props.get("_FractalRotationZ", 0.0)]
         self.u = u
@@ -157,7 +168,7 @@ class Uniforms:
 PROP_MATRICES = ("_FrustrumCorners", "_CameraInvViewMatrix", "_Positions", "_Rotations", "_Scales")
 PROP_VECTORS = ("_WorldSpaceCameraPos", "_WorldSpaceLightPos0", "_ProjectionParams", "_BackgroundColor")
 PROP_FLOATS = ("_MaxSteps", "_MaxDist", "_StepFactor", "_ContactThreshold", "_NormalSampleScale",
-               "_FractalScale", "_FractalRotationX", "_FractalRotationY", "_FractalRotationZ", "_RmSceneBody")
+               "_FractalScale", "_FractalRotationX", "_FractalRotationY", "_FractalRotationZ", "_RmSceneBody", "_RmFractalPower")
 
 
 def props_from_material(mat) -> dict:

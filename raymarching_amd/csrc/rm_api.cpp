@@ -37,6 +37,8 @@ const char *const kDeclared[] = {
     "_BackgroundColor",
     // which scene() body runs: 0 primitives (cginc:336-363), 1 menger (:295-313), 2 sierpinski (:264-293)
     "_RmSceneBody",
+    // exponent of the mandelbulb / mandelbrot bodies; 0 = the functions' defaults 7 / 2 (cginc:194,229)
+    "_RmFractalPower",
 };
 
 typedef std::array<float, 4> vec4;
@@ -124,6 +126,7 @@ void load_defaults(rm_ctx *c) {
     c->floats["_FractalRotationZ"] = 0.14f;
     c->floats["_FractalScale"] = 2.0f;
     c->floats["_RmSceneBody"] = 0.0f;
+    c->floats["_RmFractalPower"] = 0.0f;
     c->floats["_Glossiness"] = 0.2f;
     c->floats["_MaxDist"] = 50.0f;
     c->floats["_MaxSteps"] = 400.0f;
@@ -357,7 +360,8 @@ int build_params(rm_ctx *c, RmParams *U, hipStream_t stream) {
     }
     const int body = (int)getf(c, "_RmSceneBody", 0.0f);
     if (body != RM_BODY_PRIMS) {
-        if (body != RM_BODY_MENGER && body != RM_BODY_SIERPINSKI) return fail(c, RM_E_ARG, "_RmSceneBody must be 0 (primitives), 1 (menger) or 2 (sierpinski)");
+        if (body < RM_BODY_MENGER || body > RM_BODY_MANDELBROT)
+            return fail(c, RM_E_ARG, "_RmSceneBody must be 0 (primitives), 1 (menger), 2 (sierpinski), 3 (mandelbulb) or 4 (mandelbrot)");
         // the wrapper transform is slot 0 of the matrices, whatever table is set
         rm_primitive lp[4];
         legacy_prims(c, lp);
@@ -375,6 +379,8 @@ int build_params(rm_ctx *c, RmParams *U, hipStream_t stream) {
             U->f_rot[2 * i] = (float)std::cos(a);
             U->f_rot[2 * i + 1] = (float)std::sin(a);
         }
+        const float power = getf(c, "_RmFractalPower", 0.0f);
+        U->f_power = power > 0.0f ? power : (body == RM_BODY_MANDELBULB ? 7.0f : 2.0f);
         U->f_pow3 = (float)std::pow(3.0, -12.0);
         for (int i = 0; i < 16; i++) U->f_pows[i] = (float)std::pow((double)scale, -(double)i);
     }

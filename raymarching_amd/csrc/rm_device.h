@@ -127,6 +127,7 @@ struct RmParams {
     float    f_rot[6];         // cos,sin of _FractalRotationX, Y, Z (cginc:53-54)
     float    f_pow3;           // pow(3.0, -12)          (cginc:312)
     float    f_pows[16];       // pow(_FractalScale, -i) (cginc:292)
+    float    f_power;          // e of mandelbulb (cginc:194) / mandelbrot (cginc:229)
 };
 
-enum : int32_t { RM_BODY_PRIMS = 0, RM_BODY_MENGER = 1, RM_BODY_SIERPINSKI = 2 };
+enum : int32_t { RM_BODY_PRIMS = 0, RM_BODY_MENGER = 1, RM_BODY_SIERPINSKI = 2, RM_BODY_MANDELBULB = 3, RM_BODY_MANDELBROT = 4 };

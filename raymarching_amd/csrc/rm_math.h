@@ -341,6 +341,135 @@ RM_DI V3 rm_rotate_euler(const EulerV &e, V3 v) {
     return mk3(e.cz * bx - e.sz * ay, e.sz * bx + e.cz * ay, bz);                    // mz
 }
 
+// ---- canonical transcendental functions -----------------------------------------------------
+// HLSL does not bit-define sin/cos/acos/asin/atan2/pow/log, so the fractal bodies that use them
+// (cginc:194-262) have no bit-defined result in the reference.  They are fixed as float -> float
+// functions evaluated in IEEE double with +,-,*,/ and sqrt in exactly this operation order (no
+// fused multiply-add), rounded to float once: every IEEE machine produces the same bits, and each
+// result is the correctly rounded float of the true function in all sampled cases.
+#define RM_PIO2_HI 1.57079632673412561417e+00   /* first 33 bits of pi/2 */
+#define RM_PIO2_LO 6.07710050650619224932e-11   /* pi/2 - RM_PIO2_HI */
+#define RM_PI      3.14159265358979311600e+00
+#define RM_PIO2    1.57079632679489655800e+00
+#define RM_PIO4    7.85398163397448278999e-01
+#define RM_LN2     6.93147180559945286227e-01
+#define RM_LN2_HI  6.93147180369123816490e-01   /* first 32 bits of ln 2 */
+#define RM_LN2_LO  1.90821492927058770002e-10   /* ln 2 - RM_LN2_HI */
+
+RM_DI double rm_c_sin_poly(double r) {          // Taylor series on [-pi/4, pi/4], Horner on r*r
+    const double q = r * r;
+    double p = 1.0 / 355687428096000.0;
+    p = p * q - 1.0 / 1307674368000.0;
+    p = p * q + 1.0 / 6227020800.0;
+    p = p * q - 1.0 / 39916800.0;
+    p = p * q + 1.0 / 362880.0;
+    p = p * q - 1.0 / 5040.0;
+    p = p * q + 1.0 / 120.0;
+    p = p * q - 1.0 / 6.0;
+    return r + r * (q * p);
+}
+RM_DI double rm_c_cos_poly(double r) {
+    const double q = r * r;
+    double p = 1.0 / 20922789888000.0;
+    p = p * q - 1.0 / 87178291200.0;
+    p = p * q + 1.0 / 479001600.0;
+    p = p * q - 1.0 / 3628800.0;
+    p = p * q + 1.0 / 40320.0;
+    p = p * q - 1.0 / 720.0;
+    p = p * q + 1.0 / 24.0;
+    p = p * q - 0.5;
+    return 1.0 + q * p;
+}
+// sin and cos of one angle share the reduction x = k*pi/2 + r and the two series
+RM_DI void rm_c_sincos(float xf, float &sn, float &cs) {
+    const double x = (double)xf;
+    const double k = __builtin_floor(x * (1.0 / RM_PIO2) + 0.5);
+    const double r = (x - k * RM_PIO2_HI) - k * RM_PIO2_LO;
+    const int n = (int)(k - 4.0 * __builtin_floor(k * 0.25));
+    const double sp = rm_c_sin_poly(r), cp = rm_c_cos_poly(r);
+    const double vs = (n & 1) ? cp : sp, vc = (n & 1) ? sp : cp;
+    sn = (float)((n & 2) ? -vs : vs);
+    cs = (float)(((n + 1) & 2) ? -vc : vc);
+}
+RM_DI double rm_c_atan01(double t) {            // atan on [0, 1]
+    double base = 0.0, u = t;
+    if (t > 0.41421356237309503) { u = (t - 1.0) / (t + 1.0); base = RM_PIO4; }
+    const double q = u * u;
+    double p = 1.0 / 43.0;
+#pragma unroll
+    for (int n = 41; n >= 1; n -= 2) p = 1.0 / (double)n - q * p;
+    return base + u * p;
+}
+RM_DI double rm_c_atan2d(double y, double x) {
+    const double ay = __builtin_fabs(y), ax = __builtin_fabs(x);
+    double a;
+    if (ay > ax) a = RM_PIO2 - rm_c_atan01(ax / ay);
+    else if (ax > 0.0) a = rm_c_atan01(ay / ax);
+    else a = ay / ax;                           // 0/0 and NaN stay NaN
+    if (x < 0.0) a = RM_PI - a;
+    return (y < 0.0) ? -a : a;
+}
+RM_DI float rm_c_atan2(float y, float x) { return (float)rm_c_atan2d((double)y, (double)x); }
+RM_DI float rm_c_acos(float vf) {
+    const double v = (double)vf;
+    double t = 1.0 - v * v;
+    if (!(t > 0.0)) t = 0.0;
+    return (float)rm_c_atan2d(__builtin_sqrt(t), v);
+}
+RM_DI float rm_c_asin(float vf) {
+    const double v = (double)vf;
+    double t = 1.0 - v * v;
+    if (!(t > 0.0)) t = 0.0;
+    return (float)rm_c_atan2d(v, __builtin_sqrt(t));
+}
+RM_DI double rm_c_logd(double x) {              // finite x > 0
+    int e;
+    double m = __builtin_frexp(x, &e) * 2.0;
+    e -= 1;
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double s = (m - 1.0) / (m + 1.0), q = s * s;
+    double p = 1.0 / 25.0;
+#pragma unroll
+    for (int n = 23; n >= 1; n -= 2) p = 1.0 / (double)n + q * p;
+    return (double)e * RM_LN2 + 2.0 * s * p;
+}
+RM_DI double rm_c_expd(double y) {
+    if (!(y < 700.0)) return y > 0.0 ? (double)__builtin_huge_valf() : y;
+    if (y < -700.0) return 0.0;
+    const double k = __builtin_floor(y * (1.0 / RM_LN2) + 0.5);
+    const double f = (y - k * RM_LN2_HI) - k * RM_LN2_LO;
+    double p = 1.0 / 87178291200.0;
+    p = 1.0 / 6227020800.0 + f * p;
+    p = 1.0 / 479001600.0 + f * p;
+    p = 1.0 / 39916800.0 + f * p;
+    p = 1.0 / 3628800.0 + f * p;
+    p = 1.0 / 362880.0 + f * p;
+    p = 1.0 / 40320.0 + f * p;
+    p = 1.0 / 5040.0 + f * p;
+    p = 1.0 / 720.0 + f * p;
+    p = 1.0 / 120.0 + f * p;
+    p = 1.0 / 24.0 + f * p;
+    p = 1.0 / 6.0 + f * p;
+    p = 1.0 / 2.0 + f * p;
+    p = 1.0 + f * p;
+    p = 1.0 + f * p;
+    return __builtin_ldexp(p, (int)k);
+}
+RM_DI float rm_c_log(float xf) {
+    if (!(xf > 0.0f)) return xf == 0.0f ? -__builtin_huge_valf() : __builtin_nanf("");
+    if (__builtin_isinf(xf)) return xf;
+    return (float)rm_c_logd((double)xf);
+}
+// pow(x, e) for x >= 0 from ln x (so that two powers of one x share it)
+RM_DI float rm_c_pow_ln(float xf, double lnx, float ef) {
+    if (!(xf > 0.0f)) {
+        if (xf == 0.0f) return ef > 0.0f ? 0.0f : (ef == 0.0f ? 1.0f : __builtin_huge_valf());
+        return __builtin_nanf("");
+    }
+    if (__builtin_isinf(xf)) return ef > 0.0f ? xf : (ef == 0.0f ? 1.0f : 0.0f);
+    return (float)rm_c_expd((double)ef * lnx);
+}
+
 // Fractal scene: body(rotate(p - pos, q) / scale) with .w scaled by min(scale), pos/q/scale from
 // slot 0 of the three matrices.  The orbit traps (rgb) are minima of lengths; sqrt is monotonic
 // and correctly rounded here, so the minimum is taken over the squared lengths and rooted once,
@@ -419,9 +548,60 @@ struct SceneF {
         if (TRAPS) { r.x = rm_sqrt(t0); r.y = rm_sqrt(t1); r.z = rm_sqrt(t2); } else { r.x = r.y = r.z = 0.0f; }
         return r;
     }
+    // cginc:194-227 (BROT false) and cginc:229-262 (BROT true); iters = 12, bailout = 10
+    template <bool TRAPS, bool BROT> RM_DI V4 bulb(V3 p) const {
+        const float e = U.f_power, em1 = e - 1.0f;
+        V3 z = p;
+        float dr = 1.0f, r = 0.0f;
+        float t0 = 100.0f, t1 = 100.0f, t2 = 100.0f;             // bailout^2
+#pragma nounroll
+        for (int i = 0; i < 12; i++) {
+            const float r2 = z.x * z.x + z.y * z.y + z.z * z.z;
+            r = rm_sqrt(r2);
+            if (TRAPS) {
+                t0 = fminf(t0, r2);
+                if (BROT) {
+                    const float a = z.x - 1.0f, b = z.x - 2.0f;
+                    t1 = fminf(t1, a * a + z.y * z.y + z.z * z.z);
+                    t2 = fminf(t2, b * b + z.y * z.y + z.z * z.z);
+                } else {
+                    const float a = z.z - 1.0f, b = z.z - 2.0f;
+                    t1 = fminf(t1, z.x * z.x + z.y * z.y + a * a);
+                    t2 = fminf(t2, z.x * z.x + z.y * z.y + b * b);
+                }
+            }
+            if (r > 10.0f) break;
+            const float ratio = z.z / r;
+            float theta, phi;
+            if (BROT) { theta = rm_c_atan2(z.y, z.x); phi = rm_c_asin(ratio); }
+            else      { theta = rm_c_acos(ratio);     phi = rm_c_atan2(z.y, z.x); }
+            const bool plain = r > 0.0f && !__builtin_isinf(r);
+            const double lnr = plain ? rm_c_logd((double)r) : 0.0;
+            dr = rm_c_pow_ln(r, lnr, em1) * e * dr + 1.0f;
+            const float zr = rm_c_pow_ln(r, lnr, e);
+            theta = theta * e;
+            phi = phi * e;
+            float st, ct, sp, cp;
+            rm_c_sincos(theta, st, ct);
+            rm_c_sincos(phi, sp, cp);
+            if (BROT) z = mk3(zr * (ct * cp), zr * (st * cp), zr * (-sp));
+            else      z = mk3(zr * (st * cp), zr * (sp * st), zr * ct);
+            z = mk3(z.x + p.x, z.y + p.y, z.z + p.z);
+        }
+        V4 o;
+        o.w = 0.5f * rm_c_log(r) * r / dr;
+        if (TRAPS) { o.x = rm_sqrt(t0); o.y = rm_sqrt(t1); o.z = rm_sqrt(t2); } else { o.x = o.y = o.z = 0.0f; }
+        return o;
+    }
     template <bool TRAPS> RM_DI V4 eval(V3 p) const {
         const V3 l = local(p);
-        V4 o = U.body == RM_BODY_MENGER ? menger<TRAPS>(l) : sierpinski<TRAPS>(l);
+        V4 o;
+        switch (U.body) {                                        // wave-uniform
+        case RM_BODY_MENGER:     o = menger<TRAPS>(l); break;
+        case RM_BODY_SIERPINSKI: o = sierpinski<TRAPS>(l); break;
+        case RM_BODY_MANDELBULB: o = bulb<TRAPS, false>(l); break;
+        default:                 o = bulb<TRAPS, true>(l); break;
+        }
         if (!unit) o.w = o.w * P0.ms;
         return o;
     }

@@ -99,7 +99,7 @@ def _fractional_steps(case, mat):
     mat.SetFloat("_NormalSampleScale", 0.001)
 
 
-def _fractal(body, closeup, scale=None, rot=None, fscale=None):
+def _fractal(body, closeup, scale=None, rot=None, fscale=None, power=None):
     """a fractal scene() body around slot 0; closeup: camera 3.4 units from it instead of the default view"""
     def f(case, mat):
         ts = scenes.default_transforms()
@@ -118,6 +118,8 @@ def _fractal(body, closeup, scale=None, rot=None, fscale=None):
         mat.SetFloat("_RmSceneBody", body)
         if fscale is not None:
             mat.SetFloat("_FractalScale", fscale)
+        if power is not None:
+            mat.SetFloat("_RmFractalPower", power)
     return f
 
 
@@ -198,6 +200,10 @@ CASES = [
     Case("edge_inf_camera_32x18", 32, 18, setup=_edge({"_MaxSteps": 20.0}, vectors={"_WorldSpaceCameraPos": (float("inf"), 1, -11, 0)})),
     Case("tall_3x257", 3, 257),
     Case("wide_1025x2", 1025, 2),
+    Case("mandelbulb_closeup_240x135", 240, 135, setup=_fractal(3, True)),
+    Case("mandelbulb_power8_rotated_200x112", 200, 112, setup=_fractal(3, False, scale=(3.0, 3.0, 3.0), rot=quat_angle_axis(-50.0, (1, 0.3, 0.2)), power=8.0)),
+    Case("mandelbrot_closeup_240x135", 240, 135, setup=_fractal(4, True)),
+    Case("mandelbrot_power3_200x112", 200, 112, setup=_fractal(4, False, scale=(2.5, 2.5, 2.5), power=3.0)),
     Case("shadow_persp_100x100", 100, 100, kind="shadow_persp", setup=_shadow_persp),
     Case("shadow_dir_256x144", 256, 144, kind="shadow_dir", setup=_shadow_dir),
 ]

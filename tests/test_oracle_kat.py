@@ -138,6 +138,55 @@ def test_fractal_bodies_closed_forms(oracle, default_setup):      # cginc:264-31
     np.testing.assert_allclose(out[:3], tr, rtol=1e-6)
 
 
+def test_canonical_transcendentals_are_faithful(oracle):
+    """The double-evaluated sin/cos/acos/asin/atan2/log/pow that the mandelbulb bodies are defined
+    with: each must be the float nearest to libm's double result on a broad sample, and the two
+    restatements must agree bit for bit."""
+    from oracle import numpy_restatement as NP
+    l = oracle.lib()
+    rng = np.random.default_rng(7)
+
+    def same(got, want):
+        got, want = np.asarray(got, dtype=np.float32), np.asarray(want, dtype=np.float32)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+    x = rng.uniform(-70, 70, 4000).astype(np.float32)
+    same([l.rmo_c_sin(float(v)) for v in x], np.sin(x.astype(np.float64)))
+    same([l.rmo_c_cos(float(v)) for v in x], np.cos(x.astype(np.float64)))
+    same(NP.c_sin(x), np.sin(x.astype(np.float64)))
+    same(NP.c_cos(x), np.cos(x.astype(np.float64)))
+    v = rng.uniform(-1, 1, 4000).astype(np.float32)
+    v[:5] = [1, -1, 0, 0.5, -0.5]
+    same([l.rmo_c_acos(float(t)) for t in v], np.arccos(v.astype(np.float64)))
+    same([l.rmo_c_asin(float(t)) for t in v], np.arcsin(v.astype(np.float64)))
+    same(NP.c_acos(v), np.arccos(v.astype(np.float64)))
+    same(NP.c_asin(v), np.arcsin(v.astype(np.float64)))
+    y, xx = rng.normal(size=4000).astype(np.float32), rng.normal(size=4000).astype(np.float32)
+    y[:4], xx[:4] = [0, 1, -1, 0], [-1, 0, 0, 1]
+    same([l.rmo_c_atan2(float(a), float(b)) for a, b in zip(y, xx)], np.arctan2(y.astype(np.float64), xx.astype(np.float64)))
+    same(NP.c_atan2(y, xx), np.arctan2(y.astype(np.float64), xx.astype(np.float64)))
+    r = np.exp(rng.uniform(-30, 5, 4000)).astype(np.float32)
+    same([l.rmo_c_log(float(t)) for t in r], np.log(r.astype(np.float64)))
+    same(NP.c_log(r), np.log(r.astype(np.float64)))
+    for e in (7.0, 6.0, 2.0, 1.0, float(np.float32(3.7))):
+        same([l.rmo_c_pow(float(t), e) for t in r], np.power(r.astype(np.float64), e))
+        same(NP.c_pow(r, e), np.power(r.astype(np.float64), e))
+    assert l.rmo_c_pow(0.0, 7.0) == 0.0 and l.rmo_c_pow(0.0, 0.0) == 1.0 and l.rmo_c_log(0.0) == -math.inf
+    assert math.isnan(l.rmo_c_atan2(0.0, 0.0)) and math.isnan(l.rmo_c_log(-1.0))
+
+
+def test_mandelbulb_outside_the_bailout_radius(oracle):        # cginc:194-227
+    """|p| > 10: the loop leaves on its first test; .5*log(r)*r/1, traps = distances of p itself"""
+    l = oracle.lib()
+    out = f32([0, 0, 0, 0])
+    l.rmo_mandelbulb(p3(0, 0, 16), 7.0, fp(out))
+    assert out[3] == np.float32(0.5) * np.float32(math.log(16.0)) * np.float32(16)
+    assert out[:3].tolist() == [10, 10, 10]
+    l.rmo_mandelbrot(p3(12, 0, 0), 2.0, fp(out))
+    assert out[3] == np.float32(0.5) * np.float32(math.log(12.0)) * np.float32(12)
+    assert out[:3].tolist() == [10, 10, 10]
+
+
 def test_rotate_and_remap(oracle):             # cginc:62-66, 80-82
     l = oracle.lib()
     out = f32([0, 0, 0])
