@@ -24,13 +24,23 @@ RM_DI V3 mk3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; retur
 RM_DI float rm_dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
 // Correctly rounded sqrt for x == 0 or 2^-96 <= x <= 2^96 (sums of squared scene
-// coordinates are either exactly 0 or far above 2^-96).  v_sqrt_f32 is within 1 ulp
-// (off by one for ~15 % of inputs); the two exact fma residuals against the lower and
-// upper neighbour say which of the three candidates is the rounded root, and their
-// sign bits are added straight into the bit pattern, so there is no compare/select
-// and no denormal rescale.  Verified against (float)sqrt((double)x) for every binary32
-// in [2^-96, 2^96] (rm_selftest_sqrt).  9 VALU ops instead of the 16 of the generic
-// expansion.
+// coordinates are either exactly 0 or far above 2^-96) in 6 VALU ops, one of them
+// transcendental: y = v_rsq_f32(x) is within 1 ulp, g = x*y is a root estimate, the fma
+// gives its residual x - g*g exactly, and one Newton step g + r*(y/2) lands on the correctly
+// rounded root.  Verified against (float)sqrt((double)x) for every binary32 in [2^-96, 2^96]
+// and 0 on gfx950 (scripts/ubench/sqrt_exhaustive.hip; raw v_sqrt_f32 is off by one ulp for 15 %
+// of inputs).  The clamp keeps 0 * y finite at x == 0.  The generic expansion costs 16 ops.
+#ifndef RM_SQRT_V1
+RM_DI float rm_sqrt(float x) {
+    float y = fminf(__builtin_amdgcn_rsqf(x), 0x1p+100f);
+    float g = x * y;
+    float h = 0.5f * y;
+    float r = __builtin_fmaf(-g, g, x);
+    return __builtin_fmaf(r, h, g);
+}
+#else
+// earlier 9-op form: v_sqrt_f32, exact fma residuals against the lower and upper neighbour,
+// their sign bits added into the bit pattern (also exhaustively verified)
 RM_DI float rm_sqrt(float x) {
     float s = __builtin_amdgcn_sqrtf(x);
     uint32_t sb = __float_as_uint(s);
@@ -39,6 +49,7 @@ RM_DI float rm_sqrt(float x) {
     float h_up = __builtin_fmaf(__uint_as_float(sb + 1u), s, -x); // <  0: the root rounds up to sb+1
     return __uint_as_float(dn + (__float_as_uint(h_dn) >> 31) + (__float_as_uint(h_up) >> 31));
 }
+#endif
 RM_DI float rm_len3(V3 a) { return rm_sqrt(rm_dot3(a, a)); }
 RM_DI float rm_len2(float x, float y) { return rm_sqrt(x * x + y * y); }
 RM_DI float rm_lerp(float a, float b, float t) { return a + t * (b - a); }

@@ -15,6 +15,43 @@ __device__ __forceinline__ float cand_a(float x) {
     return __uint_as_float(dn - (uint32_t)m);
 }
 
+// one transcendental op: rsq, then one Newton step on g = x*y with the exact fma residual
+__device__ __forceinline__ float cand_b(float x) {
+    float y = __builtin_amdgcn_rsqf(x);
+    y = fminf(y, 0x1p+100f);                     // x == 0: keep 0 * y finite
+    float g = x * y;
+    float h = 0.5f * y;
+    float r = __builtin_fmaf(-g, g, x);
+    return __builtin_fmaf(r, h, g);
+}
+// the same with a second residual step
+__device__ __forceinline__ float cand_c(float x) {
+    float y = __builtin_amdgcn_rsqf(x);
+    y = fminf(y, 0x1p+100f);
+    float g = x * y;
+    float h = 0.5f * y;
+    float r = __builtin_fmaf(-g, g, x);
+    g = __builtin_fmaf(r, h, g);
+    r = __builtin_fmaf(-g, g, x);
+    return __builtin_fmaf(r, h, g);
+}
+// v_sqrt_f32 start, one Newton step with h = 0.5 * rsq
+__device__ __forceinline__ float cand_d(float x) {
+    float g = __builtin_amdgcn_sqrtf(x);
+    float y = fminf(__builtin_amdgcn_rsqf(x), 0x1p+100f);
+    float r = __builtin_fmaf(-g, g, x);
+    return __builtin_fmaf(r, 0.5f * y, g);
+}
+
+__global__ void check_more(uint32_t first, unsigned long long *bad) {
+    uint32_t bits = first + blockIdx.x * blockDim.x + threadIdx.x;
+    float x = __uint_as_float(bits);
+    uint32_t ref = __float_as_uint((float)sqrt((double)x));
+    if (ref != __float_as_uint(cand_b(x))) atomicAdd(bad + 0, 1ull);
+    if (ref != __float_as_uint(cand_c(x))) atomicAdd(bad + 1, 1ull);
+    if (ref != __float_as_uint(cand_d(x))) atomicAdd(bad + 2, 1ull);
+}
+
 __global__ void check(uint32_t first, unsigned long long *bad, uint32_t *example) {
     uint32_t bits = first + blockIdx.x * blockDim.x + threadIdx.x;
     float x = __uint_as_float(bits);
@@ -36,6 +73,8 @@ __global__ void raw_ulp(uint32_t first, unsigned long long *cnt) {   // how ofte
 }
 
 int main() {
+    unsigned long long *bad2, h2[3] = {0, 0, 0};
+    hipMalloc(&bad2, 24); hipMemset(bad2, 0, 24);
     unsigned long long *bad, h[6] = {0, 0, 0, 0, 0, 0};
     uint32_t *ex, hex = 0;
     hipMalloc(&bad, 48); hipMalloc(&ex, 4);
@@ -47,10 +86,14 @@ int main() {
         uint32_t n = (uint32_t)((hi - b) < (1u << 28) ? (hi - b) : (1u << 28));
         hipLaunchKernelGGL(check, dim3(n / 256), dim3(256), 0, 0, (uint32_t)b, bad, ex);
         hipLaunchKernelGGL(raw_ulp, dim3(n / 256), dim3(256), 0, 0, (uint32_t)b, bad + 1);
+        hipLaunchKernelGGL(check_more, dim3(n / 256), dim3(256), 0, 0, (uint32_t)b, bad2);
         total += n;
     }
     hipLaunchKernelGGL(check, dim3(1), dim3(256), 0, 0, 0u, bad, ex);      // 0 and the smallest denormals
+    hipLaunchKernelGGL(check_more, dim3(1), dim3(256), 0, 0, 0u, bad2);
     hipDeviceSynchronize();
+    hipMemcpy(h2, bad2, 24, hipMemcpyDeviceToHost);
+    printf("rsq+newton mismatches %llu; two steps %llu; sqrt+rsq step %llu\n", h2[0], h2[1], h2[2]);
     hipMemcpy(h, bad, 48, hipMemcpyDeviceToHost);
     hipMemcpy(&hex, ex, 4, hipMemcpyDeviceToHost);
     printf("checked %llu values: candidate mismatches %llu (example bits 0x%08x)\n", total, h[0], hex);
