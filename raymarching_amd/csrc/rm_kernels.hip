@@ -641,16 +641,21 @@ __global__ RM_LB void rm_tile_kernelN(const RmParams U) {
 }
 
 // Waves per SIMD the register allocator is asked to fit.  4 (<= 128 VGPRs) is the measured best
-// for the persistent kernel on the unrotated scene (3 starves the VALU, 5+ slows the waves that
-// carry a frame's longest tiles); the variants with per-primitive rotation keep 20 more constants
-// per primitive in registers and would spill at 128, so they run 3 waves (<= 168 VGPRs).
+// for the persistent kernel on the reference's own scene (3 starves the VALU, 5+ slows the waves
+// that carry a frame's longest tiles).  Variants that divide by a non-unit scale keep ~30 more
+// constants live and get 3 waves (<= 168 VGPRs); variants with per-primitive rotation keep ~50
+// more and get 2 (<= 256): any spill lands inside the march loop and costs far more than the
+// occupancy (rotated + scaled 4-slot scene at 1080p: 700 us with spills at 3 waves, 258 us at 2).
 #ifndef RM_Q_MIN_WAVES
 #define RM_Q_MIN_WAVES 4
 #endif
-#ifndef RM_Q_MIN_WAVES_ROT
-#define RM_Q_MIN_WAVES_ROT 3
+#ifndef RM_Q_MIN_WAVES_SCL
+#define RM_Q_MIN_WAVES_SCL 3
 #endif
-#define RM_QLB __launch_bounds__(256, (ROT ? RM_Q_MIN_WAVES_ROT : RM_Q_MIN_WAVES))
+#ifndef RM_Q_MIN_WAVES_ROT
+#define RM_Q_MIN_WAVES_ROT 2
+#endif
+#define RM_QLB __launch_bounds__(256, (ROT ? RM_Q_MIN_WAVES_ROT : (SCL == RM_SCL_UNIT ? RM_Q_MIN_WAVES : RM_Q_MIN_WAVES_SCL)))
 
 template <bool ROT, int SCL>
 __global__ RM_QLB void rm_queue_kernel4(const RmParams U) {
@@ -668,8 +673,9 @@ __global__ __launch_bounds__(256, RM_Q_MIN_WAVES_ROT) void rm_queue_kernelF(cons
     rm_queue_body(U, sc);
 }
 
+// the table walk keeps four primitives' records in flight: 2 waves per SIMD (<= 256 VGPRs) avoids spills
 template <bool ROT, int SCL>
-__global__ __launch_bounds__(256, RM_Q_MIN_WAVES) void rm_queue_kernelN(const RmParams U) {
+__global__ __launch_bounds__(256, RM_Q_MIN_WAVES_ROT) void rm_queue_kernelN(const RmParams U) {
     if (U.lds_prims) {
         PrimTable<true> t; t.T = rm_stage_table(U, (U.queue.bitmap_words + 3u) & ~3u);
         SceneN<ROT, SCL, true> sc(t, U.n_prims, (U.scene_flags & RM_SF_CSG) != 0, U.tail_ops);
@@ -682,7 +688,7 @@ __global__ __launch_bounds__(256, RM_Q_MIN_WAVES) void rm_queue_kernelN(const Rm
 }
 
 template <bool ROT, int SCL>
-__global__ __launch_bounds__(256, RM_Q_MIN_WAVES) void rm_stream_kernelN(const RmParams U) {
+__global__ __launch_bounds__(256, RM_Q_MIN_WAVES_ROT) void rm_stream_kernelN(const RmParams U) {
     if (U.lds_prims) {
         PrimTable<true> t; t.T = rm_stage_table(U, 0);
         SceneN<ROT, SCL, true> sc(t, U.n_prims, (U.scene_flags & RM_SF_CSG) != 0, U.tail_ops);
@@ -695,7 +701,7 @@ __global__ __launch_bounds__(256, RM_Q_MIN_WAVES) void rm_stream_kernelN(const R
 }
 
 template <bool ROT, int SCL>
-__global__ __launch_bounds__(256, (ROT ? RM_Q_MIN_WAVES_ROT : RM_Q_MIN_WAVES)) void rm_stream_kernel4(const RmParams U) {
+__global__ RM_QLB void rm_stream_kernel4(const RmParams U) {
     Scene4<ROT, SCL> sc(U);
     rm_stream_body(U, sc);
 }

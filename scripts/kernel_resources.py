@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Lists VGPR/SGPR counts and scratch bytes of every kernel in librmhip.so (from the code object's
+metadata), so a spill in some variant is seen at build time rather than as a slow frame.
+
+    python scripts/kernel_resources.py [path/to/librmhip.so]
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def kernel_resources(lib: str):
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "dev.co")
+        subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", lib], check=True, capture_output=True)
+        subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True, capture_output=True)
+        notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
+    out, cur = [], None
+    for line in notes.split("\n"):
+        m = re.match(r"\s+\.(name|private_segment_fixed_size|sgpr_count|vgpr_count|group_segment_fixed_size):\s+(\S+)", line)
+        if not m:
+            continue
+        k, v = m.groups()
+        if k == "name":
+            # .name comes after the fields of its kernel in some layouts; start a record at the first field instead
+            pass
+        if cur is None or k in cur:
+            cur = {}
+            out.append(cur)
+        cur[k] = v
+    for r in out:
+        r["demangled"] = short_name(r.get("name", "?"))
+    return out
+
+
+def short_name(mangled: str) -> str:
+    """rm_queue_kernel4<true, 1> from _ZN12_GLOBAL__N_116rm_queue_kernel4ILb1ELi1EEEv8RmParams"""
+    m = re.search(r"\d+(rm_[a-z_]+[4NF]?)(?:ILb([01])ELi(\d)EE)?", mangled)
+    if not m:
+        return mangled
+    if m.group(2) is None:
+        return m.group(1)
+    return f"{m.group(1)}<rot={m.group(2)}, scl={m.group(3)}>"
+
+
+def main():
+    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raymarching_amd", "librmhip.so")
+    for r in kernel_resources(lib):
+        nm = r["demangled"]
+        print(f"{nm:44s} vgpr {r.get('vgpr_count', '?'):>4s} sgpr {r.get('sgpr_count', '?'):>4s} scratch {r.get('private_segment_fixed_size', '?'):>5s} B")
+
+
+if __name__ == "__main__":
+    main()

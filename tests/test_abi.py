@@ -131,3 +131,22 @@ def test_cpp_host_mirror_builds_and_runs(tmp_path):
                     "-L" + libdir, "-lrmhip", "-Wl,-rpath," + libdir], check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     assert out.strip().endswith("ok")
+
+
+def test_kernels_do_not_spill():
+    """Register spills land inside the march loop and have cost up to 2.7x in frame time; the kernels'
+    own metadata says how much scratch each variant uses."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "scripts", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    if not os.path.exists(os.path.join(kr.LLVM, "llvm-readelf")):
+        pytest.skip("no llvm-readelf")
+    res = {r["demangled"]: r for r in kr.kernel_resources(os.path.join(ROOT, "raymarching_amd", "librmhip.so"))}
+    assert len(res) >= 39
+    for name, r in res.items():
+        scratch = int(r["private_segment_fixed_size"])
+        if name in ("rm_queue_kernel4<rot=0, scl=0>", "rm_tile_kernel4<rot=0, scl=0>", "rm_tile_kernelF"):
+            assert scratch == 0, f"{name} spills {scratch} B"           # the reference scene's kernels and the fractal kernel
+        if name.startswith(("rm_queue_kernel4", "rm_tile_kernel")):
+            assert scratch <= 96, f"{name} spills {scratch} B"           # every kernel the automatic choice can pick
