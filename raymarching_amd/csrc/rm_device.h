@@ -11,19 +11,22 @@
 //   u  = -q.xyz                      c  = q.w*q.w - dot(u,u)
 //   w2 = 2*q.w                       ms = min(scale.x, min(scale.y, scale.z))
 struct RmPrimDev {
+    // Field order = order of need: a kernel variant reads the record from LDS in 16-byte quads and
+    // the compiler drops the quads a variant never touches (unit scale: no quad 3/4; no rotation:
+    // no quad 1; distance-only evaluation: no quad 5).
     float px, py, pz;      // _Positions row
+    int32_t type;          // bits 0-7: primitive kind.  In records 4g, bit 8+l: the merge of group g's
+                           // finished subtree with stack level l is smax (see SceneN::tree)
     float ux, uy, uz;      // -q.xyz
     float c;               // q.w*q.w - dot(u,u)
     float w2;              // 2*q.w
+    float a0, a1, a2;      // sphere: r*.5 | box: b*.5 | link: le,r1,r2 | cylinder: h,r | torus: t.x,t.y
     float sx, sy, sz;      // scale
     float ms;              // min(scale)
-    float a0, a1, a2;      // sphere: r*.5 | box: b*.5 | link: le,r1,r2 | cylinder: h,r | torus: t.x,t.y
+    float rx, ry, rz;      // RN(1/scale), used when RM_PF_RCP is set
     float nsgn;            // -1 if the distance is negated (complement solid), else +1
     float cr, cg, cb;      // colour assigned after the primitive call (cginc:356-359)
-    int32_t type;          // bits 0-7: primitive kind.  In records 4g, bit 8+l: the merge of group g's
-                           // finished subtree with stack level l is smax (see SceneN::tree)
     float osgn;            // -1 if the node whose right operand starts at this primitive is smax, else +1
-    float rx, ry, rz;      // RN(1/scale), used when RM_PF_RCP is set
 };
 static_assert(sizeof(RmPrimDev) == 96, "RmPrimDev layout");
 
