@@ -452,6 +452,7 @@ def march(scene, ox, oy, oz, dx, dy, dz, depth, steps, sf, shadow=False):
     res = np.ones(n, dtype=f)
     hit = np.zeros(n, dtype=bool)
     evals = np.zeros(n, dtype=np.int32)
+    left_by_break = np.zeros(n, dtype=bool)
     active = np.arange(n)
     i = 0
     with np.errstate(all="ignore"):
@@ -468,8 +469,10 @@ def march(scene, ox, oy, oz, dx, dy, dz, depth, steps, sf, shadow=False):
             h = np.abs(dts) < contact
             hit[a[h]] = True
             far = t > depth[a]
+            left_by_break[a[h | far]] = True
             active = a[~h & ~far]
             i += 1
+    march.last_steps = evals - left_by_break          # r.steps: the loop counter after the loop (cginc:387)
     return hit, evals, dm, res
 
 
@@ -517,22 +520,62 @@ def render(props, w, h, prims=None, src=None, scene_depth=None):
         s = np.asarray(src, dtype=np.uint8).reshape(n, 4)
         col = [s[:, j].astype(f) / f(255) for j in range(3)]
 
+    # lines the reference keeps commented out in frag, switched on by properties (all off = the shader as is)
+    fx_heat, fx_view = props.get("_RmStepHeat", 0) != 0, int(props.get("_RmDebugView", 0))
+    fx_vol, fx_bounce = props.get("_RmVolumetricLight", 0) != 0, props.get("_RmBounce", 0) != 0
+    r_steps = march.last_steps.astype(f)
+    r_len, r_hit = length.copy(), hit.copy()          # the ray `r` that frag ends up with (the bounced one, if any)
+    rox, roy, roz, rrx, rry, rrz = ox.copy(), oy.copy(), oz.copy(), rdx.copy(), rdy.copy(), rdz.copy()
+    e = np.fmax(f(0), f(props["_NormalSampleScale"]))                                           # shader:51
+    sd_full = np.fmin(f(2000), f(props["_MaxDist"]))
+
+    def normal_raw(hx, hy, hz):                                                                 # shader:63-67
+        z0 = np.zeros_like(hx)
+        return (scene.eval(hx + e, hy + z0, hz + z0)[1] - scene.eval(hx - e, hy - z0, hz - z0)[1],
+                scene.eval(hx + z0, hy + e, hz + z0)[1] - scene.eval(hx - z0, hy - e, hz - z0)[1],
+                scene.eval(hx + z0, hy + z0, hz + e)[1] - scene.eval(hx - z0, hy - z0, hz - e)[1])
+
     idx = np.nonzero(hit)[0]
     ev_s = np.zeros(n, dtype=np.int32)
     if idx.size:
         t = length[idx]
         hx, hy, hz = ox[idx] + rdx[idx] * t, oy[idx] + rdy[idx] * t, oz[idx] + rdz[idx] * t     # shader:174
-        e = np.fmax(f(0), f(props["_NormalSampleScale"]))                                       # shader:51
-        z0 = np.zeros_like(hx)
-        nx = scene.eval(hx + e, hy + z0, hz + z0)[1] - scene.eval(hx - e, hy - z0, hz - z0)[1]
-        ny = scene.eval(hx + z0, hy + e, hz + z0)[1] - scene.eval(hx - z0, hy - e, hz - z0)[1]
-        nz = scene.eval(hx + z0, hy + z0, hz + e)[1] - scene.eval(hx - z0, hy - z0, hz - e)[1]
-        inv = f(1) / np.sqrt(dot(nx, ny, nz, nx, ny, nz))
-        ux, uy, uz = nx * inv, ny * inv, nz * inv
-        srgb, _ = scene.eval(hx, hy, hz, want_rgb=True)                                         # shader:193
+        nx, ny, nz = normal_raw(hx, hy, hz)
+        with np.errstate(all="ignore"):
+            inv = f(1) / np.sqrt(dot(nx, ny, nz, nx, ny, nz))
+            ux, uy, uz = nx * inv, ny * inv, nz * inv
         contact = t * f(.0025)                       # value raymarch() left in _ContactThreshold (cginc:376)
-        sx, sy, sz = hx + (ux * contact) * f(2), hy + (uy * contact) * f(2), hz + (uz * contact) * f(2)
-        sd = np.full(idx.size, np.fmin(f(2000), f(props["_MaxDist"])), dtype=f)
+        if fx_bounce:                                                                           # shader:178-187
+            with np.errstate(all="ignore"):
+                bx, by, bz = hx - (ux * contact) * f(2), hy - (uy * contact) * f(2), hz - (uz * contact) * f(2)
+                ix, iy, iz = rdx[idx], rdy[idx], rdz[idx]
+                # reflect(i, n) = i - (2*dot(i,n))*n
+                tr = f(2) * dot(ix, iy, iz, ux, uy, uz)
+                fx_, fy_, fz_ = ix - ux * tr, iy - uy * tr, iz - uz * tr
+                # refract(i, n, eta): k = 1 - eta*eta*(1 - dot(n,i)^2); k < 0 -> 0
+                eta = f(1.1)
+                dn = dot(ux, uy, uz, ix, iy, iz)
+                k = f(1) - (eta * eta) * (f(1) - dn * dn)
+                tt = eta * dn + np.sqrt(np.where(k < 0, f(0), k))
+                gx = np.where(k < 0, f(0), ix * eta - ux * tt)
+                gy = np.where(k < 0, f(0), iy * eta - uy * tt)
+                gz = np.where(k < 0, f(0), iz * eta - uz * tt)
+                inside = scene.eval(hx, hy, hz)[1] >= 0
+                nrx, nry, nrz = np.where(inside, gx, fx_), np.where(inside, gy, fy_), np.where(inside, gz, fz_)
+            bh, _, bl, _ = march(scene, bx, by, bz, nrx, nry, nrz, np.full(idx.size, sd_full, dtype=f), steps, sf)
+            r_steps[idx] = march.last_steps.astype(f)
+            r_len[idx], r_hit[idx] = bl, bh
+            rox[idx], roy[idx], roz[idx], rrx[idx], rry[idx], rrz[idx] = bx, by, bz, nrx, nry, nrz
+            with np.errstate(all="ignore"):
+                hx, hy, hz = bx + nrx * bl, by + nry * bl, bz + nrz * bl
+                nx, ny, nz = normal_raw(hx, hy, hz)
+                inv = f(1) / np.sqrt(dot(nx, ny, nz, nx, ny, nz))
+                ux, uy, uz = nx * inv, ny * inv, nz * inv
+                contact = bl * f(.0025)
+        srgb, _ = scene.eval(hx, hy, hz, want_rgb=True)                                         # shader:193
+        with np.errstate(all="ignore"):
+            sx, sy, sz = hx + (ux * contact) * f(2), hy + (uy * contact) * f(2), hz + (uz * contact) * f(2)
+        sd = np.full(idx.size, sd_full, dtype=f)
         lx, ly, lz = (np.full(idx.size, L[j], dtype=f) for j in range(3))
         _, evs, _, res = march(scene, sx, sy, sz, lx, ly, lz, sd, steps, sf, shadow=True)
         ev_s[idx] = evs
@@ -541,8 +584,35 @@ def render(props, w, h, prims=None, src=None, scene_depth=None):
             ndl = dot(ux, uy, uz, L[0], L[1], L[2]) * f(.5) + f(.5)
             nss = f(props["_NormalSampleScale"])
             ao = clamp(length3(nx / nss, ny / nss, nz / nss), 0, 1)                             # shader:125-127
+            shaded = [((srgb[j] * ndl) * shadow) * ao for j in range(3)]                        # shader:199
+            if fx_view == 1:
+                shaded = [shadow, shadow, shadow]                                               # shader:200
+            elif fx_view == 2:
+                shaded = [ux * f(.5) + f(.5), uy * f(.5) + f(.5), uz * f(.5) + f(.5)]           # shader:201
+            elif fx_view == 3:
+                v = clamp(srgb[0] * f(2.5) - f(1.75), 0, 1)                                     # shader:198
+                shaded = [v, v, v]
+            keep = r_hit[idx]
             for j in range(3):
-                col[j][idx] = ((srgb[j] * ndl) * shadow) * ao                                   # shader:199
+                col[j][idx[keep]] = shaded[j][keep]
+    with np.errstate(all="ignore"):
+        if fx_heat:                                                                             # shader:203
+            hterm = r_steps / f(100) * sf
+            col = [c + hterm for c in col]
+        if fx_vol:                                                                              # shader:206-212
+            la = np.zeros(n, dtype=f)
+            lim = np.fmin(f(5), r_len)
+            i = f(0)
+            while True:
+                act = np.nonzero(i * f(.1) < lim)[0]
+                if act.size == 0:
+                    break
+                px, py, pz = rox[act] + (rrx[act] * i) * f(.1), roy[act] + (rry[act] * i) * f(.1), roz[act] + (rrz[act] * i) * f(.1)
+                lx, ly, lz = (np.full(act.size, L[j], dtype=f) for j in range(3))
+                _, _, _, res = march(scene, px, py, pz, lx, ly, lz, np.full(act.size, sd_full, dtype=f), steps, sf, shadow=True)
+                la[act] = la[act] + res * f(.05)
+                i = i + f(1)
+            col = [c + la for c in col]
     rgba = np.empty((n, 4), dtype=np.uint8)
     for j in range(3):
         rgba[:, j] = unorm8(col[j])

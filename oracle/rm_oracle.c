@@ -489,7 +489,7 @@ static inline float scene_w(const scene_ctx *c, f3 p) {
     return o[0];
 }
 
-typedef struct { int hit; int evals; float length; float contact; } march_t;
+typedef struct { int hit; int evals; float length; float contact; int steps; /* r.steps: the loop counter after the loop (cginc:387) */ } march_t;
 
 /* ---- cginc:367-392  raymarch(ro, rd, depth, steps=2000) -------------------
  * `hit` is read uninitialised in the reference when the loop never sets it;
@@ -500,7 +500,7 @@ static inline march_t raymarch(const scene_ctx *c, f3 ro, f3 rd, float depth, fl
     depth = fminf(depth, u->max_dist);
     float steps = fminf(2000.0f, u->max_steps);
     float dm = 0.0f;
-    march_t r = {0, 0, 0.0f, contact0};
+    march_t r = {0, 0, 0.0f, contact0, 0};
     int i;
     for (i = 0; (float)i < steps; i++) {
         f3 cp = add3(ro, scl3(rd, dm));
@@ -512,6 +512,7 @@ static inline march_t raymarch(const scene_ctx *c, f3 ro, f3 rd, float depth, fl
         if (dm > depth) break;
     }
     r.length = dm;
+    r.steps = i;
     return r;
 }
 
@@ -610,7 +611,21 @@ typedef struct {
     rmo_stats st;
 } job_t;
 
-/* ---- shader:149-216  frag -------------------------------------------------- */
+/* HLSL reflect / refract, expanded once (not bit-defined by D3D):
+ *   reflect(i, n)      = i - (2*dot(i,n))*n
+ *   refract(i, n, eta) = k < 0 ? 0 : eta*i - (eta*dot(n,i) + sqrt(k))*n,  k = 1 - eta*eta*(1 - dot(n,i)^2) */
+static inline f3 hlsl_reflect(f3 i, f3 n) { return sub3(i, scl3(n, 2.0f * dot3(i, n))); }
+static inline f3 hlsl_refract(f3 i, f3 n, float eta) {
+    float d = dot3(n, i);
+    float k = 1.0f - (eta * eta) * (1.0f - d * d);
+    if (k < 0.0f) return v3(0.0f, 0.0f, 0.0f);
+    return sub3(scl3(i, eta), scl3(n, eta * d + sqrtf(k)));
+}
+
+/* ---- shader:149-216  frag --------------------------------------------------
+ * The fx_* uniforms switch on lines the reference keeps commented out: the one-bounce loop
+ * (shader:178-187), the alternative outputs (:198-201), the step-count term (:203) and the light
+ * integration along the ray (:206-212).  All zero = the shader as it stands. */
 static void frag_pixel(job_t *j, int x, int y, rmo_stats *st) {
     const scene_ctx *c = &j->sc;
     const rmo_uniforms *u = c->u;
@@ -628,18 +643,47 @@ static void frag_pixel(job_t *j, int x, int y, rmo_stats *st) {
 
     f3 col = tex;
     int sev = 0;
-    if (r.hit || u->shade_miss_pixels) {
+    const march_t primary = r;                                        /* depth / mask outputs describe the camera ray */
+    const int fx = u->fx_step_heat || u->fx_debug_view || u->fx_volumetric || u->fx_bounce;
+    if (r.hit || u->shade_miss_pixels || fx) {
         f3 hitpoint = add3(ro, scl3(rd, r.length));                   /* shader:174 */
         f3 rawnormal = getnormalraw(c, hitpoint);
         f3 normal = normalize3(rawnormal);
+        if (u->fx_bounce && r.hit) {                                  /* shader:178-187, one round */
+            ro = sub3(hitpoint, scl3(scl3(normal, r.contact), 2.0f));
+            rd = scene_w(c, hitpoint) >= 0.0f ? hlsl_refract(rd, normal, 1.1f) : hlsl_reflect(rd, normal);
+            r = raymarch(c, ro, rd, 2000.0f, r.contact);
+            hitpoint = add3(ro, scl3(rd, r.length));
+            rawnormal = getnormalraw(c, hitpoint);
+            normal = normalize3(rawnormal);
+        }
         f4 s = scene(c, hitpoint);                                    /* shader:193 */
         f3 srgb = xyz(s);
         float shadow = remap(getshadow(c, hitpoint, normal, r.contact, &sev), 0.0f, 1.0f, .25f, 1.0f);
         float ndl = dot3(normal, c->light) * .5f + .5f;
         f3 shaded = scl3(scl3(scl3(srgb, ndl), shadow), getAO(c, rawnormal));
+        if (u->fx_debug_view == 1) shaded = v3(shadow, shadow, shadow);                                    /* shader:200 */
+        if (u->fx_debug_view == 2) shaded = v3(normal.x * .5f + .5f, normal.y * .5f + .5f, normal.z * .5f + .5f);   /* :201 */
+        if (u->fx_debug_view == 3) { float v = clamp1(s.x * 2.5f - 1.75f, 0.0f, 1.0f); shaded = v3(v, v, v); }      /* :198 */
         st->sum_steps_s_all += (uint64_t)sev;
-        if (r.hit) { col = shaded; st->sum_steps_s += (uint64_t)sev; st->n_hit++; }
+        if (r.hit) col = shaded;
+        if (primary.hit) { st->sum_steps_s += (uint64_t)sev; st->n_hit++; }
     }
+    if (u->fx_step_heat) {                                            /* shader:203 */
+        float h = (float)r.steps / 100.0f * u->step_factor;
+        col = v3(col.x + h, col.y + h, col.z + h);
+    }
+    if (u->fx_volumetric) {                                           /* shader:206-212 */
+        float la = 0.0f;
+        const f3 zero = v3(0.0f, 0.0f, 0.0f);
+        for (float i = 0.0f; i * .1f < fminf(5.0f, r.length); i += 1.0f) {
+            f3 rp = add3(ro, scl3(scl3(rd, i), .1f));
+            int ev;
+            la += getshadow(c, rp, zero, r.contact, &ev) * .05f;
+        }
+        col = v3(col.x + la, col.y + la, col.z + la);
+    }
+    r.length = primary.length; r.hit = primary.hit; r.evals = primary.evals;
     if (j->rgba) {
         j->rgba[idx * 4 + 0] = unorm8(col.x);
         j->rgba[idx * 4 + 1] = unorm8(col.y);

@@ -74,6 +74,11 @@ typedef struct {
     float fractal_scale;         /* _FractalScale (cginc:12) */
     float fractal_rotation[3];   /* _FractalRotationX/Y/Z (cginc:13) */
     float fractal_power;         /* e of mandelbulb/mandelbrot; <= 0: the function's default (7 / 2) */
+    /* lines the reference keeps commented out in frag (all 0 = the shader as it stands) */
+    int32_t fx_step_heat;        /* col += r.steps / 100 * _StepFactor          (shader:203) */
+    int32_t fx_debug_view;       /* 1 shadow (shader:200), 2 normal*.5+.5 (:201), 3 clamp(scene(hitpoint).r*2.5-1.75,0,1) (:198) */
+    int32_t fx_volumetric;       /* light integration along the ray              (shader:206-212) */
+    int32_t fx_bounce;           /* one refract/reflect round                    (shader:178-187) */
 } rmo_uniforms;
 
 /* scene() bodies.  PRIMS is the reference's active code (cginc:336-363).  The fractal bodies are

@@ -30,7 +30,8 @@ class RmoUniforms(C.Structure):
                 ("smooth_k", C.c_float), ("background", C.c_float * 4),
                 ("n_prims", C.c_int32), ("prims", C.POINTER(RmoPrim)), ("shade_miss_pixels", C.c_int32),
                 ("scene_body", C.c_int32), ("fractal_scale", C.c_float), ("fractal_rotation", C.c_float * 3),
-                ("fractal_power", C.c_float)]
+                ("fractal_power", C.c_float), ("fx_step_heat", C.c_int32), ("fx_debug_view", C.c_int32),
+                ("fx_volumetric", C.c_int32), ("fx_bounce", C.c_int32)]
 
 
 class RmoStats(C.Structure):
@@ -156,6 +157,10 @@ class Uniforms:
         u.scene_body = int(props.get("_RmSceneBody", 0))
         u.fractal_scale = props.get("_FractalScale", 2.0)
         u.fractal_power = props.get("_RmFractalPower", 0.0)
+        u.fx_step_heat = int(props.get("_RmStepHeat", 0) != 0)
+        u.fx_debug_view = int(props.get("_RmDebugView", 0))
+        u.fx_volumetric = int(props.get("_RmVolumetricLight", 0) != 0)
+        u.fx_bounce = int(props.get("_RmBounce", 0) != 0)
         u.fractal_rotation[:] = [props.get("_FractalRotationX", 0.0), props.get("_FractalRotationY", 0.0),
                                  props.get("_FractalRotationZ", 0.0)]
         self.u = u
@@ -168,7 +173,8 @@ class Uniforms:
 PROP_MATRICES = ("_FrustrumCorners", "_CameraInvViewMatrix", "_Positions", "_Rotations", "_Scales")
 PROP_VECTORS = ("_WorldSpaceCameraPos", "_WorldSpaceLightPos0", "_ProjectionParams", "_BackgroundColor")
 PROP_FLOATS = ("_MaxSteps", "_MaxDist", "_StepFactor", "_ContactThreshold", "_NormalSampleScale",
-               "_FractalScale", "_FractalRotationX", "_FractalRotationY", "_FractalRotationZ", "_RmSceneBody", "_RmFractalPower")
+               "_FractalScale", "_FractalRotationX", "_FractalRotationY", "_FractalRotationZ", "_RmSceneBody", "_RmFractalPower",
+               "_RmStepHeat", "_RmDebugView", "_RmVolumetricLight", "_RmBounce")
 
 
 def props_from_material(mat) -> dict:

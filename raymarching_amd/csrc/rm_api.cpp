@@ -39,6 +39,9 @@ const char *const kDeclared[] = {
     "_RmSceneBody",
     // exponent of the mandelbulb / mandelbrot bodies; 0 = the functions' defaults 7 / 2 (cginc:194,229)
     "_RmFractalPower",
+    // lines of frag that the reference keeps commented out: col += r.steps/100*_StepFactor (shader:203), the
+    // alternative outputs (:198-201), the light integration along the ray (:206-212), the bounce loop (:178-187)
+    "_RmStepHeat", "_RmDebugView", "_RmVolumetricLight", "_RmBounce",
 };
 
 typedef std::array<float, 4> vec4;
@@ -127,6 +130,10 @@ void load_defaults(rm_ctx *c) {
     c->floats["_FractalScale"] = 2.0f;
     c->floats["_RmSceneBody"] = 0.0f;
     c->floats["_RmFractalPower"] = 0.0f;
+    c->floats["_RmStepHeat"] = 0.0f;
+    c->floats["_RmDebugView"] = 0.0f;
+    c->floats["_RmVolumetricLight"] = 0.0f;
+    c->floats["_RmBounce"] = 0.0f;
     c->floats["_Glossiness"] = 0.2f;
     c->floats["_MaxDist"] = 50.0f;
     c->floats["_MaxSteps"] = 400.0f;
@@ -385,6 +392,11 @@ int build_params(rm_ctx *c, RmParams *U, hipStream_t stream) {
         for (int i = 0; i < 16; i++) U->f_pows[i] = (float)std::pow((double)scale, -(double)i);
     }
     U->scene_flags = flags;
+    U->fx_flags = (getf(c, "_RmStepHeat", 0.0f) != 0.0f ? RM_FX_STEP_HEAT : 0u) |
+                  (getf(c, "_RmVolumetricLight", 0.0f) != 0.0f ? RM_FX_VOLUMETRIC : 0u) |
+                  (getf(c, "_RmBounce", 0.0f) != 0.0f ? RM_FX_BOUNCE : 0u);
+    U->fx_view = (int32_t)getf(c, "_RmDebugView", 0.0f);
+    if (U->fx_view < 0 || U->fx_view > 3) return fail(c, RM_E_ARG, "_RmDebugView must be 0..3");
     return RM_OK;
 }
 
@@ -490,6 +502,7 @@ int launch(rm_ctx *c, const RmParams &U, hipStream_t stream) {
     // (the fractal bodies are uniformly expensive too: measured 1.18 ms tile vs 1.57 ms queue at 1080p)
     int kernel = c->kernel != RM_KERNEL_AUTO ? c->kernel : ((U.n_prims > 0 || U.body != RM_BODY_PRIMS) ? RM_KERNEL_TILE : RM_KERNEL_QUEUE);
     if (U.body != RM_BODY_PRIMS && kernel == RM_KERNEL_STREAM) kernel = RM_KERNEL_QUEUE;      // no stream kernel for the fractal bodies
+    if (U.mode == RM_MODE_FRAG && (U.fx_flags != 0 || U.fx_view != 0)) kernel = RM_KERNEL_TILE;   // the optional frag lines exist in the tile kernels only
     if (kernel == RM_KERNEL_TILE) {
         unsigned n_blocks = rm_tile_blocks(U.w, U.rows, U.n_poses);
         int rc = ensure_partials(c, n_blocks, stream);

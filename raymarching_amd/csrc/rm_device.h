@@ -131,6 +131,11 @@ struct RmParams {
     float    f_pow3;           // pow(3.0, -12)          (cginc:312)
     float    f_pows[16];       // pow(_FractalScale, -i) (cginc:292)
     float    f_power;          // e of mandelbulb (cginc:194) / mandelbrot (cginc:229)
+    // lines of frag the reference keeps commented out (0 = the shader as it stands); tile kernels only
+    uint32_t fx_flags;         // RM_FX_*
+    int32_t  fx_view;          // 1 shadow (shader:200), 2 normal*.5+.5 (:201), 3 clamp(scene(hitpoint).r*2.5-1.75,0,1) (:198)
 };
+
+enum : uint32_t { RM_FX_STEP_HEAT = 1, RM_FX_VOLUMETRIC = 2, RM_FX_BOUNCE = 4 };
 
 enum : int32_t { RM_BODY_PRIMS = 0, RM_BODY_MENGER = 1, RM_BODY_SIERPINSKI = 2, RM_BODY_MANDELBULB = 3, RM_BODY_MANDELBROT = 4 };

@@ -34,7 +34,7 @@
 
 namespace {
 
-struct MarchResult { bool hit; int evals; float length; float contact; };
+struct MarchResult { bool hit; int evals; float length; float contact; int steps; };
 
 // cginc:367-392.  `n_steps` = number of i >= 0 with (float)i < min(2000,_MaxSteps), `depth` already
 // min'ed with _MaxDist.  The loop only carries dm; whether it ended on the contact test is
@@ -57,6 +57,9 @@ RM_DI MarchResult rm_raymarch(const S &sc, V3 ro, V3 rd, float depth, int n_step
     r.hit = adts < contact;
     r.contact = contact;
     r.length = dm;
+    // r.steps = the loop counter after the loop (cginc:387): one less than the evaluations if the loop
+    // was left by a break
+    r.steps = (r.evals > 0 && (adts < contact || dm > depth)) ? r.evals - 1 : r.evals;
     return r;
 }
 
@@ -172,6 +175,102 @@ RM_DI PixelOut rm_compute_pixel(const RmParams &U, const S &sc, int x, int yl, i
     return out;
 }
 
+// frag with the lines the reference keeps commented out switched on by U.fx_flags / U.fx_view:
+// the one-bounce loop (shader:178-187), the alternative outputs (:198-201), the step-count term
+// (:203) and the light integration along the ray (:206-212).  Used only by the *_fx kernels, so the
+// default kernels carry none of this.  depth / mask / counters describe the camera ray.
+RM_DI V3 rm_reflect(V3 i, V3 n) { const float t = 2.0f * rm_dot3(i, n); return mk3(i.x - n.x * t, i.y - n.y * t, i.z - n.z * t); }
+RM_DI V3 rm_refract(V3 i, V3 n, float eta) {
+    const float d = rm_dot3(n, i);
+    const float k = 1.0f - (eta * eta) * (1.0f - d * d);
+    if (k < 0.0f) return mk3(0.0f, 0.0f, 0.0f);
+    const float t = eta * d + sqrtf(k);
+    return mk3(i.x * eta - n.x * t, i.y * eta - n.y * t, i.z * eta - n.z * t);
+}
+
+template <class S>
+RM_DI V3 rm_normal_raw(const RmParams &U, const S &sc, V3 hp) {
+    const float e = U.nss;
+    V3 raw = mk3(0.0f, 0.0f, 0.0f);
+#pragma nounroll
+    for (int a = 0; a < 3; a++) {
+        const V3 o = mk3(a == 0 ? e : 0.0f, a == 1 ? e : 0.0f, a == 2 ? e : 0.0f);
+        const float d = sc.w(mk3(hp.x + o.x, hp.y + o.y, hp.z + o.z)) - sc.w(mk3(hp.x - o.x, hp.y - o.y, hp.z - o.z));
+        raw.x = a == 0 ? d : raw.x; raw.y = a == 1 ? d : raw.y; raw.z = a == 2 ? d : raw.z;
+    }
+    return raw;
+}
+
+template <class S>
+RM_DI PixelOut rm_compute_pixel_fx(const RmParams &U, const S &sc, int x, int yl, int pose,
+                                   unsigned &c_hit, unsigned &c_p, unsigned &c_s) {
+    PixelOut out;
+    V3 ro, rd;
+    float depth;
+    size_t gidx;
+    rm_setup_ray(U, x, yl, pose, ro, rd, depth, gidx, out.oidx);
+    const float sf = rm_vgpr(U.step_factor);
+    MarchResult r = rm_raymarch(sc, ro, rd, depth, U.n_steps, sf);
+    c_p += (unsigned)r.evals;
+    c_hit += r.hit ? 1u : 0u;
+    out.depth = r.length;
+    out.hit = r.hit ? 1u : 0u;
+    out.rgba = 0;
+    if (U.mode != RM_MODE_FRAG) return out;
+
+    V3 col;
+    if (U.src) {
+        const uint32_t t = reinterpret_cast<const uint32_t *>(U.src)[gidx];
+        col = mk3((float)(t & 255u) / 255.0f, (float)((t >> 8) & 255u) / 255.0f, (float)((t >> 16) & 255u) / 255.0f);
+    } else {
+        col = mk3(U.bg[0], U.bg[1], U.bg[2]);
+    }
+    const V3 L = mk3(rm_vgpr(U.light[0]), rm_vgpr(U.light[1]), rm_vgpr(U.light[2]));
+    if (r.hit) {
+        V3 hp = mk3(ro.x + rd.x * r.length, ro.y + rd.y * r.length, ro.z + rd.z * r.length);
+        V3 raw = rm_normal_raw(U, sc, hp);
+        V3 n = rm_normalize(raw);
+        if (U.fx_flags & RM_FX_BOUNCE) {
+            ro = mk3(hp.x - (n.x * r.contact) * 2.0f, hp.y - (n.y * r.contact) * 2.0f, hp.z - (n.z * r.contact) * 2.0f);
+            rd = sc.w(hp) >= 0.0f ? rm_refract(rd, n, 1.1f) : rm_reflect(rd, n);
+            r = rm_raymarch(sc, ro, rd, fminf(2000.0f, U.max_dist), U.n_steps, sf);
+            hp = mk3(ro.x + rd.x * r.length, ro.y + rd.y * r.length, ro.z + rd.z * r.length);
+            raw = rm_normal_raw(U, sc, hp);
+            n = rm_normalize(raw);
+        }
+        V4 s = sc.full(hp);
+        int sev = 0;
+        float sh = rm_getshadow(sc, hp, n, L, r.contact, U.shadow_depth, U.n_steps, sf, sev);
+        c_s += (unsigned)sev;
+        if (r.hit) {                                           // the bounced ray may have missed: then tex stays
+            float shadow = sh * 0.75f + .25f;
+            float ndl = rm_dot3(n, L) * .5f + .5f;
+            float ao = rm_clamp01(rm_len3(mk3(raw.x / U.nss_raw, raw.y / U.nss_raw, raw.z / U.nss_raw)));
+            col = mk3(((s.x * ndl) * shadow) * ao, ((s.y * ndl) * shadow) * ao, ((s.z * ndl) * shadow) * ao);
+            if (U.fx_view == 1) col = mk3(shadow, shadow, shadow);
+            if (U.fx_view == 2) col = mk3(n.x * .5f + .5f, n.y * .5f + .5f, n.z * .5f + .5f);
+            if (U.fx_view == 3) { const float v = rm_clamp01(s.x * 2.5f - 1.75f); col = mk3(v, v, v); }
+        }
+    }
+    if (U.fx_flags & RM_FX_STEP_HEAT) {
+        const float h = (float)r.steps / 100.0f * U.step_factor;
+        col = mk3(col.x + h, col.y + h, col.z + h);
+    }
+    if (U.fx_flags & RM_FX_VOLUMETRIC) {
+        float la = 0.0f;
+        const float lim = fminf(5.0f, r.length);
+        const V3 zero = mk3(0.0f, 0.0f, 0.0f);
+        for (float i = 0.0f; i * .1f < lim; i += 1.0f) {
+            const V3 rp = mk3(ro.x + (rd.x * i) * .1f, ro.y + (rd.y * i) * .1f, ro.z + (rd.z * i) * .1f);
+            int ev = 0;
+            la += rm_getshadow(sc, rp, zero, L, r.contact, U.shadow_depth, U.n_steps, sf, ev) * .05f;
+        }
+        col = mk3(col.x + la, col.y + la, col.z + la);
+    }
+    out.rgba = rm_unorm8(col.x) | (rm_unorm8(col.y) << 8) | (rm_unorm8(col.z) << 16) | 0xFF000000u;
+    return out;
+}
+
 // one dword of colour, one of depth and one byte of mask per pixel; a wave writes an 8x8 tile
 // as eight 32-byte row segments per plane
 RM_DI void rm_store_pixel(const RmParams &U, const PixelOut &o) {
@@ -189,7 +288,7 @@ RM_DI unsigned rm_wave_sum(unsigned v) {
 // ---- kernel A: one launch block per image tile -------------------------------------------
 // One thread = one pixel.  A wave covers an 8x8 pixel tile (neighbouring rays take similar
 // step counts), a block RM_BWX x RM_BWY such tiles.  blockIdx.z = pose.
-template <class S>
+template <bool FX = false, class S>
 RM_DI void rm_pixel(const RmParams &U, const S &sc) {
     __shared__ unsigned int s_cnt[3];
     const int tid = threadIdx.x;
@@ -202,7 +301,9 @@ RM_DI void rm_pixel(const RmParams &U, const S &sc) {
     const int lane = tid & 63, wv = tid >> 6;
     const int x  = blockIdx.x * (8 * RM_BWX) + (wv % RM_BWX) * 8 + (lane & 7);
     const int yl = blockIdx.y * (8 * RM_BWY) + (wv / RM_BWX) * 8 + (lane >> 3);
-    if (x < U.w && yl < U.rows) rm_store_pixel(U, rm_compute_pixel(U, sc, x, yl, (int)blockIdx.z, c_hit, c_p, c_s));
+    if (x < U.w && yl < U.rows)
+        rm_store_pixel(U, FX ? rm_compute_pixel_fx(U, sc, x, yl, (int)blockIdx.z, c_hit, c_p, c_s)
+                             : rm_compute_pixel(U, sc, x, yl, (int)blockIdx.z, c_hit, c_p, c_s));
 
     // Counters: per-wave sums by cross-lane shuffles, per-block sums in LDS, then ONE plain
     // store per counter into this block's own slot.  No global atomics: same-address atomics
@@ -612,6 +713,12 @@ __global__ RM_LB void rm_tile_kernel4(const RmParams U) {
     rm_pixel(U, sc);
 }
 
+template <bool ROT, int SCL>
+__global__ RM_LB void rm_tile_kernel4_fx(const RmParams U) {
+    Scene4<ROT, SCL> sc(U);
+    rm_pixel<true>(U, sc);
+}
+
 // The N-primitive table is staged into LDS once per workgroup (96 B per primitive, up to
 // RM_LDS_PRIMS of them): every lane then reads the same record, which the LDS serves as a
 // broadcast into VGPRs -- no scalar-load latency per primitive and no SGPR operands in the
@@ -663,10 +770,27 @@ __global__ RM_QLB void rm_queue_kernel4(const RmParams U) {
     rm_queue_body(U, sc);
 }
 
+template <bool ROT, int SCL>
+__global__ RM_LB void rm_tile_kernelN_fx(const RmParams U) {
+    if (U.lds_prims) {
+        PrimTable<true> t; t.T = rm_stage_table(U, 0);
+        SceneN<ROT, SCL, true> sc(t, U.n_prims, (U.scene_flags & RM_SF_CSG) != 0, U.tail_ops);
+        rm_pixel<true>(U, sc);
+    } else {
+        PrimTable<false> t; t.T = U.prim_table;
+        SceneN<ROT, SCL, false> sc(t, U.n_prims, (U.scene_flags & RM_SF_CSG) != 0, U.tail_ops);
+        rm_pixel<true>(U, sc);
+    }
+}
+
 // fractal scene() bodies: one kernel each, the slot-0 transform is specialised by wave-uniform branches
 __global__ RM_LB void rm_tile_kernelF(const RmParams U) {
     SceneF sc(U);
     rm_pixel(U, sc);
+}
+__global__ RM_LB void rm_tile_kernelF_fx(const RmParams U) {
+    SceneF sc(U);
+    rm_pixel<true>(U, sc);
 }
 __global__ __launch_bounds__(256, RM_Q_MIN_WAVES_ROT) void rm_queue_kernelF(const RmParams U) {
     SceneF sc(U);
@@ -742,8 +866,15 @@ hipError_t launch_queue_variant(const RmParams &U, unsigned blocks, hipStream_t 
 
 template <bool ROT, int SCL>
 hipError_t launch_variant(const RmParams &U, dim3 grid, hipStream_t stream) {
-    if (U.n_prims > 0) hipLaunchKernelGGL((rm_tile_kernelN<ROT, SCL>), grid, dim3(RM_BLOCK), (size_t)U.lds_prims * sizeof(RmPrimDev), stream, U);
-    else               hipLaunchKernelGGL((rm_tile_kernel4<ROT, SCL>), grid, dim3(RM_BLOCK), 0, stream, U);
+    const bool fx = U.fx_flags != 0 || U.fx_view != 0;
+    const size_t lds = (size_t)U.lds_prims * sizeof(RmPrimDev);
+    if (U.n_prims > 0) {
+        if (fx) hipLaunchKernelGGL((rm_tile_kernelN_fx<ROT, SCL>), grid, dim3(RM_BLOCK), lds, stream, U);
+        else    hipLaunchKernelGGL((rm_tile_kernelN<ROT, SCL>), grid, dim3(RM_BLOCK), lds, stream, U);
+    } else {
+        if (fx) hipLaunchKernelGGL((rm_tile_kernel4_fx<ROT, SCL>), grid, dim3(RM_BLOCK), 0, stream, U);
+        else    hipLaunchKernelGGL((rm_tile_kernel4<ROT, SCL>), grid, dim3(RM_BLOCK), 0, stream, U);
+    }
     return hipGetLastError();
 }
 
@@ -811,7 +942,8 @@ hipError_t rm_launch_tiles(const RmParams &U, hipStream_t stream) {
     dim3 grid((unsigned)((U.w + 8 * RM_BWX - 1) / (8 * RM_BWX)), (unsigned)((U.rows + 8 * RM_BWY - 1) / (8 * RM_BWY)), (unsigned)U.n_poses);
     if (grid.y > 65535u || grid.z > 65535u) return hipErrorInvalidValue;
     if (U.body != RM_BODY_PRIMS) {
-        hipLaunchKernelGGL(rm_tile_kernelF, grid, dim3(RM_BLOCK), 0, stream, U);
+        if (U.fx_flags != 0 || U.fx_view != 0) hipLaunchKernelGGL(rm_tile_kernelF_fx, grid, dim3(RM_BLOCK), 0, stream, U);
+        else                                   hipLaunchKernelGGL(rm_tile_kernelF, grid, dim3(RM_BLOCK), 0, stream, U);
         return hipGetLastError();
     }
     const bool rot = !(U.scene_flags & RM_SF_IDENT_ROT);

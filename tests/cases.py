@@ -134,6 +134,20 @@ def _edge(floats=None, vectors=None):
     return f
 
 
+def _fx(floats, inner=None, bg=None):
+    """the default scene (or another setup) with some of frag's commented-out lines switched on"""
+    def f(case, mat):
+        if inner:
+            inner(case, mat)
+        else:
+            _base(mat, case.w, case.h)
+        for k, v in floats.items():
+            mat.SetFloat(k, v)
+        if bg is not None:
+            mat.SetVector("_BackgroundColor", np.asarray(bg, dtype=F))
+    return f
+
+
 def _shadow_persp(case, mat):
     _base(mat, case.w, case.h)
     sm = ShadowMap(scenes.shadow_camera(case.w, case.h), mat)
@@ -204,6 +218,19 @@ CASES = [
     Case("mandelbulb_power8_rotated_200x112", 200, 112, setup=_fractal(3, False, scale=(3.0, 3.0, 3.0), rot=quat_angle_axis(-50.0, (1, 0.3, 0.2)), power=8.0)),
     Case("mandelbrot_closeup_240x135", 240, 135, setup=_fractal(4, True)),
     Case("mandelbrot_power3_200x112", 200, 112, setup=_fractal(4, False, scale=(2.5, 2.5, 2.5), power=3.0)),
+    # frag's commented-out lines (shader:178-187, 198-203, 206-212) switched on
+    Case("fx_step_heat_320x180", 320, 180, setup=_fx({"_RmStepHeat": 1.0})),
+    Case("fx_view_shadow_160x90", 160, 90, setup=_fx({"_RmDebugView": 1.0})),
+    Case("fx_view_normal_160x90", 160, 90, setup=_fx({"_RmDebugView": 2.0})),
+    Case("fx_view_red_160x90", 160, 90, setup=_fx({"_RmDebugView": 3.0})),
+    # the integrated light is ~2.5 in free space: a background of -2.4 keeps the sum inside [0,1] where it shows
+    Case("fx_volumetric_96x54", 96, 54, setup=_fx({"_RmVolumetricLight": 1.0}, bg=(-2.4, -2.3, -2.2, 1.0))),
+    Case("fx_bounce_320x180", 320, 180, setup=_fx({"_RmBounce": 1.0})),
+    Case("fx_all_transformed_128x72", 128, 72, setup=_fx({"_RmBounce": 1.0, "_RmStepHeat": 1.0, "_RmVolumetricLight": 1.0},
+                                                         inner=_transformed(False), bg=(-2.6, -2.5, -2.4, 1.0))),
+    Case("fx_heat_bounce_stress13_160x90", 160, 90, setup=_fx({"_RmBounce": 1.0, "_RmStepHeat": 1.0}, inner=_stress),
+         prims=scenes.stress_primitives(13, seed=0x5EED000D)),
+    Case("fx_bounce_view_menger_160x90", 160, 90, setup=_fx({"_RmBounce": 1.0, "_RmDebugView": 2.0}, inner=_fractal(1, True))),
     Case("shadow_persp_100x100", 100, 100, kind="shadow_persp", setup=_shadow_persp),
     Case("shadow_dir_256x144", 256, 144, kind="shadow_dir", setup=_shadow_dir),
 ]
