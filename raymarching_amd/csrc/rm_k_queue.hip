@@ -1,0 +1,63 @@
+// rm_k_queue.hip -- persistent waves pulling 8x8 tiles from the ordered queue.
+#include "rm_kernels_common.h"
+
+namespace {
+
+template <bool ROT, int SCL>
+__global__ RM_QLB void rm_queue_kernel4(const RmParams U) {
+    Scene4<ROT, SCL> sc(U);
+    rm_queue_body(U, sc);
+}
+
+__global__ __launch_bounds__(256, RM_Q_MIN_WAVES_ROT) void rm_queue_kernelF(const RmParams U) {
+    SceneF sc(U);
+    rm_queue_body(U, sc);
+}
+
+// the table walk keeps four primitives' records in flight: 2 waves per SIMD (<= 256 VGPRs) avoids spills
+template <bool ROT, int SCL>
+__global__ __launch_bounds__(256, RM_Q_MIN_WAVES_ROT) void rm_queue_kernelN(const RmParams U) {
+    if (U.lds_prims) {
+        PrimTable<true> t; t.T = rm_stage_table(U, (U.queue.bitmap_words + 3u) & ~3u);
+        SceneN<ROT, SCL, true> sc(t, U.n_prims, (U.scene_flags & RM_SF_CSG) != 0, U.tail_ops);
+        rm_queue_body(U, sc);
+    } else {
+        PrimTable<false> t; t.T = U.prim_table;
+        SceneN<ROT, SCL, false> sc(t, U.n_prims, (U.scene_flags & RM_SF_CSG) != 0, U.tail_ops);
+        rm_queue_body(U, sc);
+    }
+}
+
+template <bool ROT, int SCL>
+hipError_t launch_queue_variant(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu) {
+    if (blocks_per_cu) {
+        int n4 = 0, nN = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, rm_queue_kernel4<ROT, SCL>, 256, (size_t)U.queue.bitmap_words * 4);
+        if (e != hipSuccess) return e;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nN, rm_queue_kernelN<ROT, SCL>, 256, (size_t)((U.queue.bitmap_words + 3u) & ~3u) * 4 + (size_t)U.lds_prims * sizeof(RmPrimDev));
+        if (e != hipSuccess) return e;
+        blocks_per_cu[0] = n4; blocks_per_cu[1] = nN;
+        return hipSuccess;
+    }
+    const size_t lds = (size_t)((U.queue.bitmap_words + 3u) & ~3u) * 4 + (size_t)U.lds_prims * sizeof(RmPrimDev);
+    if (U.n_prims > 0) hipLaunchKernelGGL((rm_queue_kernelN<ROT, SCL>), dim3(blocks), dim3(256), lds, stream, U);
+    else               hipLaunchKernelGGL((rm_queue_kernel4<ROT, SCL>), dim3(blocks), dim3(256), lds, stream, U);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t rm_launch_queue(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu) {
+    if (U.body != RM_BODY_PRIMS) {
+        const size_t lds = (size_t)U.queue.bitmap_words * 4;
+        if (blocks_per_cu) {
+            int n = 0;
+            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rm_queue_kernelF, 256, lds);
+            blocks_per_cu[0] = blocks_per_cu[1] = n;
+            return e;
+        }
+        hipLaunchKernelGGL(rm_queue_kernelF, dim3(blocks), dim3(256), lds, stream, U);
+        return hipGetLastError();
+    }
+    RM_DISPATCH_VARIANT(launch_queue_variant, U, U, blocks, stream, blocks_per_cu);
+}

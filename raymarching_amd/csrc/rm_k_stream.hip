@@ -1,0 +1,46 @@
+// rm_k_stream.hip -- persistent waves with lane-level ray compaction (experimental).
+#include "rm_kernels_common.h"
+
+namespace {
+
+template <bool ROT, int SCL>
+__global__ __launch_bounds__(256, RM_Q_MIN_WAVES_ROT) void rm_stream_kernelN(const RmParams U) {
+    if (U.lds_prims) {
+        PrimTable<true> t; t.T = rm_stage_table(U, 0);
+        SceneN<ROT, SCL, true> sc(t, U.n_prims, (U.scene_flags & RM_SF_CSG) != 0, U.tail_ops);
+        rm_stream_body(U, sc);
+    } else {
+        PrimTable<false> t; t.T = U.prim_table;
+        SceneN<ROT, SCL, false> sc(t, U.n_prims, (U.scene_flags & RM_SF_CSG) != 0, U.tail_ops);
+        rm_stream_body(U, sc);
+    }
+}
+
+template <bool ROT, int SCL>
+__global__ RM_QLB void rm_stream_kernel4(const RmParams U) {
+    Scene4<ROT, SCL> sc(U);
+    rm_stream_body(U, sc);
+}
+
+template <bool ROT, int SCL>
+hipError_t launch_stream_variant(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu) {
+    const size_t lds = (size_t)U.lds_prims * sizeof(RmPrimDev);
+    if (blocks_per_cu) {
+        int n4 = 0, nN = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, rm_stream_kernel4<ROT, SCL>, 256, 0);
+        if (e != hipSuccess) return e;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nN, rm_stream_kernelN<ROT, SCL>, 256, lds);
+        if (e != hipSuccess) return e;
+        blocks_per_cu[0] = n4; blocks_per_cu[1] = nN;
+        return hipSuccess;
+    }
+    if (U.n_prims > 0) hipLaunchKernelGGL((rm_stream_kernelN<ROT, SCL>), dim3(blocks), dim3(256), lds, stream, U);
+    else               hipLaunchKernelGGL((rm_stream_kernel4<ROT, SCL>), dim3(blocks), dim3(256), 0, stream, U);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t rm_launch_stream(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu) {
+    RM_DISPATCH_VARIANT(launch_stream_variant, U, U, blocks, stream, blocks_per_cu);
+}

@@ -1,4 +1,5 @@
-// rm_kernels.hip -- gfx950 kernels of librmhip: the fused per-pixel march
+#pragma once
+// rm_kernels_common.h -- gfx950 kernels of librmhip: the fused per-pixel march
 // (primary ray + central-difference normal + colour + soft-shadow march + shade)
 // that replaces pass 0 of the reference's fragment shader
 // (Assets/Raymarching.shader:149-216 with Assets/Raymarching.cginc:334-392), and the
@@ -688,37 +689,6 @@ RM_DI void rm_stream_body(const RmParams &U, const S &sc) {
     }
 }
 
-// sums the per-block counter slots of the last launch: out[0..2] = n_hit, primary evals, shadow evals
-__global__ __launch_bounds__(1024) void rm_reduce_stats_kernel(const unsigned *__restrict__ partials, unsigned n_blocks,
-                                                               unsigned long long *__restrict__ out) {
-    __shared__ unsigned long long s[3];
-    if (threadIdx.x < 3) s[threadIdx.x] = 0ull;
-    __syncthreads();
-    unsigned long long a0 = 0, a1 = 0, a2 = 0;
-    for (unsigned b = threadIdx.x; b < n_blocks; b += 1024) {
-        a0 += partials[RM_SLOT_WORDS * b]; a1 += partials[RM_SLOT_WORDS * b + 1]; a2 += partials[RM_SLOT_WORDS * b + 2];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o);
-    }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&s[0], a0); atomicAdd(&s[1], a1); atomicAdd(&s[2], a2); }
-    __syncthreads();
-    if (threadIdx.x < 3) out[threadIdx.x] = s[threadIdx.x];
-}
-
-template <bool ROT, int SCL>
-__global__ RM_LB void rm_tile_kernel4(const RmParams U) {
-    Scene4<ROT, SCL> sc(U);
-    rm_pixel(U, sc);
-}
-
-template <bool ROT, int SCL>
-__global__ RM_LB void rm_tile_kernel4_fx(const RmParams U) {
-    Scene4<ROT, SCL> sc(U);
-    rm_pixel<true>(U, sc);
-}
-
 // The N-primitive table is staged into LDS once per workgroup (96 B per primitive, up to
 // RM_LDS_PRIMS of them): every lane then reads the same record, which the LDS serves as a
 // broadcast into VGPRs -- no scalar-load latency per primitive and no SGPR operands in the
@@ -732,19 +702,6 @@ RM_DI RmLdsPrimPtr rm_stage_table(const RmParams &U, unsigned lds_word_offset) {
     for (unsigned i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
     return (RmLdsPrimPtr)(base);
-}
-
-template <bool ROT, int SCL>
-__global__ RM_LB void rm_tile_kernelN(const RmParams U) {
-    if (U.lds_prims) {
-        PrimTable<true> t; t.T = rm_stage_table(U, 0);
-        SceneN<ROT, SCL, true> sc(t, U.n_prims, (U.scene_flags & RM_SF_CSG) != 0, U.tail_ops);
-        rm_pixel(U, sc);
-    } else {
-        PrimTable<false> t; t.T = U.prim_table;
-        SceneN<ROT, SCL, false> sc(t, U.n_prims, (U.scene_flags & RM_SF_CSG) != 0, U.tail_ops);
-        rm_pixel(U, sc);
-    }
 }
 
 // Waves per SIMD the register allocator is asked to fit.  4 (<= 128 VGPRs) is the measured best
@@ -764,196 +721,26 @@ __global__ RM_LB void rm_tile_kernelN(const RmParams U) {
 #endif
 #define RM_QLB __launch_bounds__(256, (ROT ? RM_Q_MIN_WAVES_ROT : (SCL == RM_SCL_UNIT ? RM_Q_MIN_WAVES : RM_Q_MIN_WAVES_SCL)))
 
-template <bool ROT, int SCL>
-__global__ RM_QLB void rm_queue_kernel4(const RmParams U) {
-    Scene4<ROT, SCL> sc(U);
-    rm_queue_body(U, sc);
-}
-
-template <bool ROT, int SCL>
-__global__ RM_LB void rm_tile_kernelN_fx(const RmParams U) {
-    if (U.lds_prims) {
-        PrimTable<true> t; t.T = rm_stage_table(U, 0);
-        SceneN<ROT, SCL, true> sc(t, U.n_prims, (U.scene_flags & RM_SF_CSG) != 0, U.tail_ops);
-        rm_pixel<true>(U, sc);
-    } else {
-        PrimTable<false> t; t.T = U.prim_table;
-        SceneN<ROT, SCL, false> sc(t, U.n_prims, (U.scene_flags & RM_SF_CSG) != 0, U.tail_ops);
-        rm_pixel<true>(U, sc);
-    }
-}
-
-// fractal scene() bodies: one kernel each, the slot-0 transform is specialised by wave-uniform branches
-__global__ RM_LB void rm_tile_kernelF(const RmParams U) {
-    SceneF sc(U);
-    rm_pixel(U, sc);
-}
-__global__ RM_LB void rm_tile_kernelF_fx(const RmParams U) {
-    SceneF sc(U);
-    rm_pixel<true>(U, sc);
-}
-__global__ __launch_bounds__(256, RM_Q_MIN_WAVES_ROT) void rm_queue_kernelF(const RmParams U) {
-    SceneF sc(U);
-    rm_queue_body(U, sc);
-}
-
-// the table walk keeps four primitives' records in flight: 2 waves per SIMD (<= 256 VGPRs) avoids spills
-template <bool ROT, int SCL>
-__global__ __launch_bounds__(256, RM_Q_MIN_WAVES_ROT) void rm_queue_kernelN(const RmParams U) {
-    if (U.lds_prims) {
-        PrimTable<true> t; t.T = rm_stage_table(U, (U.queue.bitmap_words + 3u) & ~3u);
-        SceneN<ROT, SCL, true> sc(t, U.n_prims, (U.scene_flags & RM_SF_CSG) != 0, U.tail_ops);
-        rm_queue_body(U, sc);
-    } else {
-        PrimTable<false> t; t.T = U.prim_table;
-        SceneN<ROT, SCL, false> sc(t, U.n_prims, (U.scene_flags & RM_SF_CSG) != 0, U.tail_ops);
-        rm_queue_body(U, sc);
-    }
-}
-
-template <bool ROT, int SCL>
-__global__ __launch_bounds__(256, RM_Q_MIN_WAVES_ROT) void rm_stream_kernelN(const RmParams U) {
-    if (U.lds_prims) {
-        PrimTable<true> t; t.T = rm_stage_table(U, 0);
-        SceneN<ROT, SCL, true> sc(t, U.n_prims, (U.scene_flags & RM_SF_CSG) != 0, U.tail_ops);
-        rm_stream_body(U, sc);
-    } else {
-        PrimTable<false> t; t.T = U.prim_table;
-        SceneN<ROT, SCL, false> sc(t, U.n_prims, (U.scene_flags & RM_SF_CSG) != 0, U.tail_ops);
-        rm_stream_body(U, sc);
-    }
-}
-
-template <bool ROT, int SCL>
-__global__ RM_QLB void rm_stream_kernel4(const RmParams U) {
-    Scene4<ROT, SCL> sc(U);
-    rm_stream_body(U, sc);
-}
-
-template <bool ROT, int SCL>
-hipError_t launch_stream_variant(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu) {
-    const size_t lds = (size_t)U.lds_prims * sizeof(RmPrimDev);
-    if (blocks_per_cu) {
-        int n4 = 0, nN = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, rm_stream_kernel4<ROT, SCL>, 256, 0);
-        if (e != hipSuccess) return e;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nN, rm_stream_kernelN<ROT, SCL>, 256, lds);
-        if (e != hipSuccess) return e;
-        blocks_per_cu[0] = n4; blocks_per_cu[1] = nN;
-        return hipSuccess;
-    }
-    if (U.n_prims > 0) hipLaunchKernelGGL((rm_stream_kernelN<ROT, SCL>), dim3(blocks), dim3(256), lds, stream, U);
-    else               hipLaunchKernelGGL((rm_stream_kernel4<ROT, SCL>), dim3(blocks), dim3(256), 0, stream, U);
-    return hipGetLastError();
-}
-
-template <bool ROT, int SCL>
-hipError_t launch_queue_variant(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu) {
-    if (blocks_per_cu) {
-        int n4 = 0, nN = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, rm_queue_kernel4<ROT, SCL>, 256, (size_t)U.queue.bitmap_words * 4);
-        if (e != hipSuccess) return e;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nN, rm_queue_kernelN<ROT, SCL>, 256, (size_t)((U.queue.bitmap_words + 3u) & ~3u) * 4 + (size_t)U.lds_prims * sizeof(RmPrimDev));
-        if (e != hipSuccess) return e;
-        blocks_per_cu[0] = n4; blocks_per_cu[1] = nN;
-        return hipSuccess;
-    }
-    const size_t lds = (size_t)((U.queue.bitmap_words + 3u) & ~3u) * 4 + (size_t)U.lds_prims * sizeof(RmPrimDev);
-    if (U.n_prims > 0) hipLaunchKernelGGL((rm_queue_kernelN<ROT, SCL>), dim3(blocks), dim3(256), lds, stream, U);
-    else               hipLaunchKernelGGL((rm_queue_kernel4<ROT, SCL>), dim3(blocks), dim3(256), lds, stream, U);
-    return hipGetLastError();
-}
-
-template <bool ROT, int SCL>
-hipError_t launch_variant(const RmParams &U, dim3 grid, hipStream_t stream) {
-    const bool fx = U.fx_flags != 0 || U.fx_view != 0;
-    const size_t lds = (size_t)U.lds_prims * sizeof(RmPrimDev);
-    if (U.n_prims > 0) {
-        if (fx) hipLaunchKernelGGL((rm_tile_kernelN_fx<ROT, SCL>), grid, dim3(RM_BLOCK), lds, stream, U);
-        else    hipLaunchKernelGGL((rm_tile_kernelN<ROT, SCL>), grid, dim3(RM_BLOCK), lds, stream, U);
-    } else {
-        if (fx) hipLaunchKernelGGL((rm_tile_kernel4_fx<ROT, SCL>), grid, dim3(RM_BLOCK), 0, stream, U);
-        else    hipLaunchKernelGGL((rm_tile_kernel4<ROT, SCL>), grid, dim3(RM_BLOCK), 0, stream, U);
-    }
-    return hipGetLastError();
-}
-
-}  // namespace
-
-unsigned rm_slot_words() { return RM_SLOT_WORDS; }
-
-unsigned rm_tile_blocks(int w, int rows, int n_poses) {
-    return (unsigned)((w + 8 * RM_BWX - 1) / (8 * RM_BWX)) * (unsigned)((rows + 8 * RM_BWY - 1) / (8 * RM_BWY)) * (unsigned)n_poses;
-}
-
-hipError_t rm_reduce_stats(const unsigned *partials, unsigned n_blocks, unsigned long long *out, hipStream_t stream) {
-    hipLaunchKernelGGL(rm_reduce_stats_kernel, dim3(1), dim3(1024), 0, stream, partials, n_blocks, out);
-    return hipGetLastError();
-}
-
-// variant index 0..5 = (rot ? 3 : 0) + scl
-static int variant_index(const RmParams &U, bool &rot, int &scl) {
+// kernel variant of a scene: rotation yes/no, scale unit / reciprocal-exact / true division; index 0..5
+inline int rm_scene_variant(const RmParams &U, bool &rot, int &scl) {
     rot = !(U.scene_flags & RM_SF_IDENT_ROT);
     scl = (U.scene_flags & RM_SF_UNIT_SCALE) ? RM_SCL_UNIT : (U.scene_flags & RM_SF_RCP) ? RM_SCL_RCP : RM_SCL_DIV;
     return (rot ? 3 : 0) + scl;
 }
 
-hipError_t rm_launch_queue(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu) {
-    if (U.body != RM_BODY_PRIMS) {
-        const size_t lds = (size_t)U.queue.bitmap_words * 4;
-        if (blocks_per_cu) {
-            int n = 0;
-            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rm_queue_kernelF, 256, lds);
-            blocks_per_cu[0] = blocks_per_cu[1] = n;
-            return e;
-        }
-        hipLaunchKernelGGL(rm_queue_kernelF, dim3(blocks), dim3(256), lds, stream, U);
-        return hipGetLastError();
-    }
-    bool rot; int scl;
-    variant_index(U, rot, scl);
-    if (rot) {
-        if (scl == RM_SCL_UNIT) return launch_queue_variant<true, RM_SCL_UNIT>(U, blocks, stream, blocks_per_cu);
-        if (scl == RM_SCL_RCP)  return launch_queue_variant<true, RM_SCL_RCP>(U, blocks, stream, blocks_per_cu);
-        return launch_queue_variant<true, RM_SCL_DIV>(U, blocks, stream, blocks_per_cu);
-    }
-    if (scl == RM_SCL_UNIT) return launch_queue_variant<false, RM_SCL_UNIT>(U, blocks, stream, blocks_per_cu);
-    if (scl == RM_SCL_RCP)  return launch_queue_variant<false, RM_SCL_RCP>(U, blocks, stream, blocks_per_cu);
-    return launch_queue_variant<false, RM_SCL_DIV>(U, blocks, stream, blocks_per_cu);
-}
+// calls F<ROT, SCL>::run(args...) for the variant the scene needs
+#define RM_DISPATCH_VARIANT(F, U, ...)                                                   \
+    do {                                                                                 \
+        bool rot_; int scl_;                                                             \
+        rm_scene_variant(U, rot_, scl_);                                                 \
+        if (rot_) {                                                                      \
+            if (scl_ == RM_SCL_UNIT) return F<true, RM_SCL_UNIT>(__VA_ARGS__);           \
+            if (scl_ == RM_SCL_RCP)  return F<true, RM_SCL_RCP>(__VA_ARGS__);            \
+            return F<true, RM_SCL_DIV>(__VA_ARGS__);                                     \
+        }                                                                                \
+        if (scl_ == RM_SCL_UNIT) return F<false, RM_SCL_UNIT>(__VA_ARGS__);              \
+        if (scl_ == RM_SCL_RCP)  return F<false, RM_SCL_RCP>(__VA_ARGS__);               \
+        return F<false, RM_SCL_DIV>(__VA_ARGS__);                                        \
+    } while (0)
 
-hipError_t rm_launch_stream(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu) {
-    bool rot; int scl;
-    variant_index(U, rot, scl);
-    if (rot) {
-        if (scl == RM_SCL_UNIT) return launch_stream_variant<true, RM_SCL_UNIT>(U, blocks, stream, blocks_per_cu);
-        if (scl == RM_SCL_RCP)  return launch_stream_variant<true, RM_SCL_RCP>(U, blocks, stream, blocks_per_cu);
-        return launch_stream_variant<true, RM_SCL_DIV>(U, blocks, stream, blocks_per_cu);
-    }
-    if (scl == RM_SCL_UNIT) return launch_stream_variant<false, RM_SCL_UNIT>(U, blocks, stream, blocks_per_cu);
-    if (scl == RM_SCL_RCP)  return launch_stream_variant<false, RM_SCL_RCP>(U, blocks, stream, blocks_per_cu);
-    return launch_stream_variant<false, RM_SCL_DIV>(U, blocks, stream, blocks_per_cu);
-}
-
-int rm_variant_index(const RmParams &U) { bool r; int s; return U.body != RM_BODY_PRIMS ? 6 : variant_index(U, r, s); }
-
-hipError_t rm_launch_tiles(const RmParams &U, hipStream_t stream) {
-    if (U.w <= 0 || U.rows <= 0 || U.n_poses <= 0) return hipErrorInvalidValue;
-    dim3 grid((unsigned)((U.w + 8 * RM_BWX - 1) / (8 * RM_BWX)), (unsigned)((U.rows + 8 * RM_BWY - 1) / (8 * RM_BWY)), (unsigned)U.n_poses);
-    if (grid.y > 65535u || grid.z > 65535u) return hipErrorInvalidValue;
-    if (U.body != RM_BODY_PRIMS) {
-        if (U.fx_flags != 0 || U.fx_view != 0) hipLaunchKernelGGL(rm_tile_kernelF_fx, grid, dim3(RM_BLOCK), 0, stream, U);
-        else                                   hipLaunchKernelGGL(rm_tile_kernelF, grid, dim3(RM_BLOCK), 0, stream, U);
-        return hipGetLastError();
-    }
-    const bool rot = !(U.scene_flags & RM_SF_IDENT_ROT);
-    const int scl = (U.scene_flags & RM_SF_UNIT_SCALE) ? RM_SCL_UNIT : (U.scene_flags & RM_SF_RCP) ? RM_SCL_RCP : RM_SCL_DIV;
-    if (rot) {
-        if (scl == RM_SCL_UNIT) return launch_variant<true, RM_SCL_UNIT>(U, grid, stream);
-        if (scl == RM_SCL_RCP)  return launch_variant<true, RM_SCL_RCP>(U, grid, stream);
-        return launch_variant<true, RM_SCL_DIV>(U, grid, stream);
-    }
-    if (scl == RM_SCL_UNIT) return launch_variant<false, RM_SCL_UNIT>(U, grid, stream);
-    if (scl == RM_SCL_RCP)  return launch_variant<false, RM_SCL_RCP>(U, grid, stream);
-    return launch_variant<false, RM_SCL_DIV>(U, grid, stream);
-}
+}  // namespace

@@ -8,6 +8,8 @@ enum { RM_KERNEL_AUTO = 0, RM_KERNEL_TILE = 1, RM_KERNEL_QUEUE = 2, RM_KERNEL_ST
 
 // one-thread-per-pixel tile kernel over U.w x U.rows x U.n_poses
 hipError_t rm_launch_tiles(const RmParams &U, hipStream_t stream);
+// the same with frag's optional lines (U.fx_flags / U.fx_view); called by rm_launch_tiles with its grid
+hipError_t rm_launch_tiles_fx(const RmParams &U, unsigned grid_x, unsigned grid_y, unsigned grid_z, hipStream_t stream);
 
 // 32-bit words per counter slot
 unsigned rm_slot_words();

@@ -1,7 +1,6 @@
 #!/bin/bash
-# Developer tool: builds A/B variants of librmhip under gpurun_out-independent names
-# (raymarching_amd/variants/librmhip_<tag>.so) from -D flag sets.
-#   scripts/build_variants.sh tag1 "-DRM_BWX=1 -DRM_BWY=1" tag2 "-DRM_MIN_WAVES=8" ...
+# Developer tool: builds A/B variants of librmhip (raymarching_amd/variants/librmhip_<tag>.so) from -D flag sets.
+#   scripts/build_variants.sh tag1 "-DRM_BWX=1 -DRM_BWY=1" tag2 "-DRM_Q_MIN_WAVES=3" ...
 set -e
 cd "$(dirname "$0")/../raymarching_amd/csrc"
 mkdir -p ../variants
@@ -9,7 +8,13 @@ FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-functio
 [ -f rm_api.o ] || /opt/rocm/bin/hipcc $FLAGS -c rm_api.cpp -o rm_api.o
 while [ $# -ge 2 ]; do
   tag=$1; defs=$2; shift 2
-  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $defs -c rm_kernels.hip -o ../variants/k_$tag.o &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/librmhip_$tag.so ../variants/k_$tag.o rm_api.o && echo built $tag ) &
+  objs=""
+  for tu in tile tile_fx queue stream; do
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $defs -c rm_k_$tu.hip -o ../variants/k_${tag}_$tu.o &
+    objs="$objs ../variants/k_${tag}_$tu.o"
+  done
+  wait
+  api=rm_api.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/librmhip_$tag.so $objs $api && echo built $tag
+  rm -f $objs
 done
-wait

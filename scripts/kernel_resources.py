@@ -14,12 +14,20 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 
 def kernel_resources(lib: str):
+    notes = ""
     with tempfile.TemporaryDirectory() as d:
-        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "dev.co")
+        fat = os.path.join(d, "fat.bin")
         subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", lib], check=True, capture_output=True)
-        subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}",
-                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True, capture_output=True)
-        notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
+        blob = open(fat, "rb").read()
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"            # one bundle per translation unit, concatenated in the section
+        starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+        for k, a in enumerate(starts):
+            part, co = os.path.join(d, f"part{k}.bin"), os.path.join(d, f"dev{k}.co")
+            with open(part, "wb") as fh:
+                fh.write(blob[a:starts[k + 1] if k + 1 < len(starts) else len(blob)])
+            subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={part}",
+                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True, capture_output=True)
+            notes += subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
     out, cur = [], None
     for line in notes.split("\n"):
         m = re.match(r"\s+\.(name|private_segment_fixed_size|sgpr_count|vgpr_count|group_segment_fixed_size):\s+(\S+)", line)
@@ -40,7 +48,7 @@ def kernel_resources(lib: str):
 
 def short_name(mangled: str) -> str:
     """rm_queue_kernel4<true, 1> from _ZN12_GLOBAL__N_116rm_queue_kernel4ILb1ELi1EEEv8RmParams"""
-    m = re.search(r"\d+(rm_[a-z_]+[4NF]?)(?:ILb([01])ELi(\d)EE)?", mangled)
+    m = re.search(r"\d+(rm_[a-z_]+[4NF]?(?:_fx)?)(?:ILb([01])ELi(\d)EE)?", mangled)
     if not m:
         return mangled
     if m.group(2) is None:
