@@ -1,4 +1,4 @@
-// rm_launch.h -- host-callable launchers implemented in rm_kernels.hip.
+// rm_launch.h -- host-callable launchers implemented in rm_k_tile.hip, rm_k_tile_fx.hip, rm_k_queue.hip, rm_k_stream.hip.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "rm_device.h"
