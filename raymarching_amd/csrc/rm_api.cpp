@@ -97,6 +97,37 @@ int fail(rm_ctx *c, int code, const std::string &msg) {
             return fail((c), RM_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// Makes the context's device current for one entry point and puts the caller's device back on return:
+// a plugin must not leave the host thread on another GPU than it found it.
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    hipError_t enter(int device) {
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) return e;
+        if (prev != device) {
+            e = hipSetDevice(device);
+            switched = e == hipSuccess;
+        }
+        return e;
+    }
+    ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+};
+
+// No C++ exception may cross the C ABI (allocation failures of the property maps, strings, vectors).
+#define RM_TRY try {
+#define RM_CATCH(c)                                                              \
+    } catch (const std::bad_alloc &) {                                           \
+        return fail_noexcept((c), RM_E_NOMEM, "out of host memory");             \
+    } catch (...) {                                                              \
+        return fail_noexcept((c), RM_E_ARG, "unexpected C++ exception");         \
+    }
+
+int fail_noexcept(rm_ctx *c, int code, const char *msg) noexcept {
+    try { if (c) c->err = msg; } catch (...) {}
+    return code;
+}
+
 mat4 mat_identity() {
     mat4 m{};
     m[0] = m[5] = m[10] = m[15] = 1.0f;
@@ -260,8 +291,8 @@ void make_view(const mat4 &fc, const mat4 &c2w, const float cam_pos[3], RmView *
     corner_world(c2w, fc, 3, v->bl);
 }
 
+// first use of the device (the caller has made it current through a DeviceScope)
 int ensure_device(rm_ctx *c) {
-    RM_HIP(c, hipSetDevice(c->device));
     if (c->dev_ready) return RM_OK;
     RM_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     RM_HIP(c, hipMalloc((void **)&c->d_stats, 4 * sizeof(unsigned long long)));
@@ -421,7 +452,9 @@ int ensure_partials(rm_ctx *c, unsigned slots, hipStream_t stream) {
 
 int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, bool streamk) {
     const uint32_t tx = (uint32_t)(P.w + RM_TW - 1) / RM_TW, ty = (uint32_t)(P.rows + RM_TH - 1) / RM_TH;
-    const uint32_t n_tiles = tx * ty * (uint32_t)P.n_poses;
+    const uint64_t n_tiles64 = (uint64_t)tx * ty * (uint64_t)P.n_poses;
+    if (n_tiles64 > 0x7fffffffull) return fail(c, RM_E_RANGE, "more than 2^31 tiles in one launch: split the pose batch");
+    const uint32_t n_tiles = (uint32_t)n_tiles64;
     const int vi = rm_variant_index(P), tab = P.n_prims > 0 ? 1 : 0;
     int (*occ)[2] = streamk ? c->occ_stream : c->occ;
     if (occ[vi][tab] == 0) {
@@ -529,18 +562,26 @@ extern "C" {
 const char *rm_version(void) { return "rmhip 0.1 (gfx950)"; }
 
 rm_ctx *rm_create(int hip_device) {
-    if (hip_device < 0) { g_create_error = "negative device index"; return nullptr; }
-    rm_ctx *c = new (std::nothrow) rm_ctx();
-    if (!c) { g_create_error = "out of memory"; return nullptr; }
-    c->device = hip_device;
-    load_defaults(c);
-    return c;
+    rm_ctx *c = nullptr;
+    try {
+        if (hip_device < 0) { g_create_error = "negative device index"; return nullptr; }
+        c = new (std::nothrow) rm_ctx();
+        if (!c) { g_create_error = "out of memory"; return nullptr; }
+        c->device = hip_device;
+        load_defaults(c);
+        return c;
+    } catch (...) {
+        delete c;
+        try { g_create_error = "out of memory"; } catch (...) {}
+        return nullptr;
+    }
 }
 
 void rm_destroy(rm_ctx *c) {
     if (!c) return;
     if (c->dev_ready) {
-        (void)hipSetDevice(c->device);
+        DeviceScope ds;
+        (void)ds.enter(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         if (c->last_stream) (void)hipStreamSynchronize(c->last_stream);
         for (int i = 0; i < 5; i++) if (c->d_stage[i]) (void)hipFree(c->d_stage[i]);
@@ -557,63 +598,82 @@ void rm_destroy(rm_ctx *c) {
 const char *rm_last_error(rm_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
 int rm_set_float(rm_ctx *c, const char *name, float v) {
+    RM_TRY
     if (!c || !name) return fail(c, RM_E_ARG, "rm_set_float: null argument");
     c->floats[name] = v;
     return RM_OK;
+    RM_CATCH(c)
 }
 int rm_set_int(rm_ctx *c, const char *name, int v) {
+    RM_TRY
     // Unity 2018 keeps SetInt values in the material's float table
     if (!c || !name) return fail(c, RM_E_ARG, "rm_set_int: null argument");
     c->floats[name] = (float)v;
     return RM_OK;
+    RM_CATCH(c)
 }
 int rm_set_vector(rm_ctx *c, const char *name, const float v[4]) {
+    RM_TRY
     if (!c || !name || !v) return fail(c, RM_E_ARG, "rm_set_vector: null argument");
     c->vectors[name] = {v[0], v[1], v[2], v[3]};
     return RM_OK;
+    RM_CATCH(c)
 }
 int rm_set_matrix(rm_ctx *c, const char *name, const float m[16]) {
+    RM_TRY
     if (!c || !name || !m) return fail(c, RM_E_ARG, "rm_set_matrix: null argument");
     mat4 a;
     std::memcpy(a.data(), m, sizeof(float) * 16);
     c->matrices[name] = a;
     return RM_OK;
+    RM_CATCH(c)
 }
 int rm_get_float(rm_ctx *c, const char *name, float *v) {
+    RM_TRY
     if (!c || !name || !v) return fail(c, RM_E_ARG, "rm_get_float: null argument");
     auto it = c->floats.find(name);
     if (it == c->floats.end()) return fail(c, RM_E_ARG, std::string("no float property ") + name);
     *v = it->second;
     return RM_OK;
+    RM_CATCH(c)
 }
 int rm_get_int(rm_ctx *c, const char *name, int *v) {
+    RM_TRY
     float f;
     if (!v) return fail(c, RM_E_ARG, "rm_get_int: null argument");
     int rc = rm_get_float(c, name, &f);
     if (rc == RM_OK) *v = (int)f;
     return rc;
+    RM_CATCH(c)
 }
 int rm_get_vector(rm_ctx *c, const char *name, float v[4]) {
+    RM_TRY
     if (!c || !name || !v) return fail(c, RM_E_ARG, "rm_get_vector: null argument");
     auto it = c->vectors.find(name);
     if (it == c->vectors.end()) return fail(c, RM_E_ARG, std::string("no vector property ") + name);
     std::memcpy(v, it->second.data(), sizeof(float) * 4);
     return RM_OK;
+    RM_CATCH(c)
 }
 int rm_get_matrix(rm_ctx *c, const char *name, float m[16]) {
+    RM_TRY
     if (!c || !name || !m) return fail(c, RM_E_ARG, "rm_get_matrix: null argument");
     auto it = c->matrices.find(name);
     if (it == c->matrices.end()) return fail(c, RM_E_ARG, std::string("no matrix property ") + name);
     std::memcpy(m, it->second.data(), sizeof(float) * 16);
     return RM_OK;
+    RM_CATCH(c)
 }
 int rm_has_property(rm_ctx *c, const char *name) {
+    RM_TRY
     if (!c || !name) return 0;
     for (const char *d : kDeclared) if (std::strcmp(d, name) == 0) return 1;
     return 0;
+    RM_CATCH(c)
 }
 
 int rm_set_primitives(rm_ctx *c, const rm_primitive *prims, int n) {
+    RM_TRY
     if (!c || n < 0 || (n > 0 && !prims)) return fail(c, RM_E_ARG, "rm_set_primitives: bad argument");
     if (n > RM_MAX_PRIMS) return fail(c, RM_E_RANGE, "more than RM_MAX_PRIMS primitives");
     for (int i = 0; i < n; i++)
@@ -622,13 +682,16 @@ int rm_set_primitives(rm_ctx *c, const rm_primitive *prims, int n) {
     c->prims.assign(prims, prims + n);
     c->prims_dirty = true;
     return RM_OK;
+    RM_CATCH(c)
 }
 
 int rm_set_kernel(rm_ctx *c, int variant) {
+    RM_TRY
     if (!c) return RM_E_ARG;
     if (variant != RM_KERNEL_AUTO && variant != RM_KERNEL_TILE && variant != RM_KERNEL_QUEUE && variant != RM_KERNEL_STREAM) return fail(c, RM_E_ARG, "unknown kernel variant");
     c->kernel = variant;
     return RM_OK;
+    RM_CATCH(c)
 }
 
 int rm_band_rows(int h, int band_rows, int part, int n_parts) {
@@ -645,12 +708,15 @@ int rm_band_rows(int h, int band_rows, int part, int n_parts) {
 
 int rm_blit_bands_device(rm_ctx *c, const void *d_src, const void *d_sdepth, void *d_rgba, void *d_depth, void *d_hit,
                          int w, int h, int band_rows, int part, int n_parts, void *hip_stream) {
+    RM_TRY
     if (!c) return RM_E_ARG;
     int rc = check_size(c, w, h);
     if (rc) return rc;
     int rows = rm_band_rows(h, band_rows, part, n_parts);
     if (rows < 0) return fail(c, RM_E_ARG, "rm_blit_bands_device: bad band arguments");
     if (rows == 0) return RM_OK;
+    DeviceScope ds;
+    RM_HIP(c, ds.enter(c->device));
     if ((rc = ensure_device(c))) return rc;
     hipStream_t stream = (hipStream_t)hip_stream;
     RmParams U;
@@ -661,21 +727,27 @@ int rm_blit_bands_device(rm_ctx *c, const void *d_src, const void *d_sdepth, voi
     U.src = (const uint8_t *)d_src; U.sdepth = (const float *)d_sdepth;
     U.dst_rgba = (uint8_t *)d_rgba; U.dst_depth = (float *)d_depth; U.dst_hit = (uint8_t *)d_hit;
     return launch(c, U, stream);
+    RM_CATCH(c)
 }
 
 int rm_blit_device(rm_ctx *c, const void *d_src, const void *d_sdepth, void *d_rgba, void *d_depth, void *d_hit,
                    int w, int h, void *hip_stream) {
+    RM_TRY
     if (!c) return RM_E_ARG;
     return rm_blit_bands_device(c, d_src, d_sdepth, d_rgba, d_depth, d_hit, w, h, h > 0 ? h : 1, 0, 1, hip_stream);
+    RM_CATCH(c)
 }
 
 int rm_blit_poses_device(rm_ctx *c, int n_poses, const float *fcs, const float *c2ws, const float *cam_pos,
                          void *d_rgba, void *d_depth, void *d_hit, int w, int h, void *hip_stream) {
+    RM_TRY
     if (!c) return RM_E_ARG;
     if (n_poses <= 0 || !fcs || !c2ws || !cam_pos) return fail(c, RM_E_ARG, "rm_blit_poses_device: bad argument");
     if (n_poses > 65535) return fail(c, RM_E_RANGE, "more than 65535 poses in one call");
     int rc = check_size(c, w, h);
     if (rc) return rc;
+    DeviceScope ds;
+    RM_HIP(c, ds.enter(c->device));
     if ((rc = ensure_device(c))) return rc;
     hipStream_t stream = (hipStream_t)hip_stream;
     RmParams U;
@@ -697,12 +769,16 @@ int rm_blit_poses_device(rm_ctx *c, int n_poses, const float *fcs, const float *
     U.mode = RM_MODE_FRAG;
     U.dst_rgba = (uint8_t *)d_rgba; U.dst_depth = (float *)d_depth; U.dst_hit = (uint8_t *)d_hit;
     return launch(c, U, stream);
+    RM_CATCH(c)
 }
 
 int rm_blit(rm_ctx *c, const uint8_t *src, const float *sdepth, uint8_t *rgba, float *depth, uint8_t *hit, int w, int h) {
+    RM_TRY
     if (!c) return RM_E_ARG;
     int rc = check_size(c, w, h);
     if (rc) return rc;
+    DeviceScope ds;
+    RM_HIP(c, ds.enter(c->device));
     if ((rc = ensure_device(c))) return rc;
     size_t n = (size_t)w * (size_t)h;
     if (src)    { if ((rc = stage(c, 0, n * 4))) return rc; RM_HIP(c, hipMemcpyAsync(c->d_stage[0], src, n * 4, hipMemcpyHostToDevice, c->stream)); }
@@ -719,12 +795,16 @@ int rm_blit(rm_ctx *c, const uint8_t *src, const float *sdepth, uint8_t *rgba, f
     if (hit)   RM_HIP(c, hipMemcpyAsync(hit, c->d_stage[4], n, hipMemcpyDeviceToHost, c->stream));
     RM_HIP(c, hipStreamSynchronize(c->stream));
     return RM_OK;
+    RM_CATCH(c)
 }
 
 static int depth_pass_device(rm_ctx *c, int mode, const float corners[12], const float forward[3],
                              void *d_depth, void *d_hit, int w, int h, void *hip_stream) {
+    RM_TRY
     int rc = check_size(c, w, h);
     if (rc) return rc;
+    DeviceScope ds;
+    RM_HIP(c, ds.enter(c->device));
     if ((rc = ensure_device(c))) return rc;
     hipStream_t stream = (hipStream_t)hip_stream;
     RmParams U;
@@ -737,12 +817,16 @@ static int depth_pass_device(rm_ctx *c, int mode, const float corners[12], const
     }
     U.dst_depth = (float *)d_depth; U.dst_hit = (uint8_t *)d_hit;
     return launch(c, U, stream);
+    RM_CATCH(c)
 }
 
 static int depth_pass_host(rm_ctx *c, int mode, const float corners[12], const float forward[3], float *depth, int w, int h) {
+    RM_TRY
     if (!depth) return fail(c, RM_E_ARG, "null destination");
     int rc = check_size(c, w, h);
     if (rc) return rc;
+    DeviceScope ds;
+    RM_HIP(c, ds.enter(c->device));
     if ((rc = ensure_device(c))) return rc;
     size_t n = (size_t)w * (size_t)h;
     if ((rc = stage(c, 3, n * 4))) return rc;
@@ -750,31 +834,42 @@ static int depth_pass_host(rm_ctx *c, int mode, const float corners[12], const f
     RM_HIP(c, hipMemcpyAsync(depth, c->d_stage[3], n * 4, hipMemcpyDeviceToHost, c->stream));
     RM_HIP(c, hipStreamSynchronize(c->stream));
     return RM_OK;
+    RM_CATCH(c)
 }
 
 int rm_shadowmap_render_device(rm_ctx *c, void *d_depth, void *d_hit, int w, int h, void *hip_stream) {
+    RM_TRY
     if (!c) return RM_E_ARG;
     return depth_pass_device(c, RM_MODE_DEPTH_PERSP, nullptr, nullptr, d_depth, d_hit, w, h, hip_stream);
+    RM_CATCH(c)
 }
 int rm_shadowmap_render(rm_ctx *c, float *depth, int w, int h) {
+    RM_TRY
     if (!c) return RM_E_ARG;
     return depth_pass_host(c, RM_MODE_DEPTH_PERSP, nullptr, nullptr, depth, w, h);
+    RM_CATCH(c)
 }
 int rm_shadowmap_directional_device(rm_ctx *c, const float corners[12], const float forward[3], void *d_depth,
                                     void *d_hit, int w, int h, void *hip_stream) {
+    RM_TRY
     if (!c) return RM_E_ARG;
     if (!corners || !forward) return fail(c, RM_E_ARG, "null corners/forward");
     return depth_pass_device(c, RM_MODE_DEPTH_ORTHO, corners, forward, d_depth, d_hit, w, h, hip_stream);
+    RM_CATCH(c)
 }
 int rm_shadowmap_directional(rm_ctx *c, const float corners[12], const float forward[3], float *depth, int w, int h) {
+    RM_TRY
     if (!c) return RM_E_ARG;
     if (!corners || !forward) return fail(c, RM_E_ARG, "null corners/forward");
     return depth_pass_host(c, RM_MODE_DEPTH_ORTHO, corners, forward, depth, w, h);
+    RM_CATCH(c)
 }
 
 int rm_debug_counter_slots(rm_ctx *c, uint32_t *out, int max_words, int *words_per_slot, int *n_slots) {
+    RM_TRY
     if (!c || !c->have_last) return fail(c, RM_E_ARG, "rm_debug_counter_slots: no blit has run");
-    RM_HIP(c, hipSetDevice(c->device));
+    DeviceScope ds;
+    RM_HIP(c, ds.enter(c->device));
     RM_HIP(c, hipStreamSynchronize(c->last_stream));
     size_t words = (size_t)c->last_blocks * rm_slot_words();
     if (words_per_slot) *words_per_slot = (int)rm_slot_words();
@@ -784,12 +879,15 @@ int rm_debug_counter_slots(rm_ctx *c, uint32_t *out, int max_words, int *words_p
         RM_HIP(c, hipMemcpy(out, c->d_partials, words * 4, hipMemcpyDeviceToHost));
     }
     return RM_OK;
+    RM_CATCH(c)
 }
 
 int rm_get_stats(rm_ctx *c, rm_stats *out) {
+    RM_TRY
     if (!c || !out) return fail(c, RM_E_ARG, "rm_get_stats: null argument");
     if (!c->have_last) return fail(c, RM_E_ARG, "rm_get_stats: no blit has run");
-    RM_HIP(c, hipSetDevice(c->device));
+    DeviceScope ds;
+    RM_HIP(c, ds.enter(c->device));
     RM_HIP(c, rm_reduce_stats(c->d_partials, c->last_blocks, c->d_stats, c->last_stream));
     RM_HIP(c, hipStreamSynchronize(c->last_stream));
     unsigned long long v[4];
@@ -799,6 +897,7 @@ int rm_get_stats(rm_ctx *c, rm_stats *out) {
     out->sum_steps_p = v[1];
     out->sum_steps_s = v[2];
     return RM_OK;
+    RM_CATCH(c)
 }
 
 }  // extern "C"
