@@ -78,6 +78,9 @@ struct rm_ctx {
     int occ[7][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};   // resident blocks per CU by kernel variant (6 = fractal)
     int occ_stream[7][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
 
+    int inv_w_for = 0, inv_h_for = 0;       // frame sizes the reciprocals below were verified for
+    float inv_w = 0.0f, inv_h = 0.0f;
+
     hipStream_t last_stream = nullptr;
     uint64_t last_pixels = 0;
     bool have_last = false;
@@ -431,6 +434,27 @@ int build_params(rm_ctx *c, RmParams *U, hipStream_t stream) {
     return RM_OK;
 }
 
+// RN(1/n) if q0 = x*r, q = fma(fma(-q0, n, x), r, q0) equals x / n for every pixel centre x = i + 0.5,
+// i < n (checked here, once per size, with the same fused operations the kernel uses); else 0
+float exact_reciprocal_for_centres(int n) {
+    const float fn = (float)n, r = 1.0f / fn;
+    for (int i = 0; i < n; i++) {
+        const float x = (float)i + 0.5f;
+        const float q0 = x * r;
+        const float q = std::fma(std::fma(-q0, fn, x), r, q0);
+        if (q != x / fn) return 0.0f;
+    }
+    return r;
+}
+
+void frame_reciprocals(rm_ctx *c, int w, int h, RmParams *U) {
+    if (c->inv_w_for != w) { c->inv_w = exact_reciprocal_for_centres(w); c->inv_w_for = w; }
+    if (c->inv_h_for != h) { c->inv_h = exact_reciprocal_for_centres(h); c->inv_h_for = h; }
+    const bool ok = c->inv_w != 0.0f && c->inv_h != 0.0f;
+    U->inv_w = ok ? c->inv_w : 0.0f;
+    U->inv_h = ok ? c->inv_h : 0.0f;
+}
+
 int check_size(rm_ctx *c, int w, int h) {
     if (w <= 0 || h <= 0) return fail(c, RM_E_ARG, "width and height must be positive");
     if (w > 32768 || h > 32768) return fail(c, RM_E_RANGE, "frame larger than 32768 x 32768");
@@ -484,6 +508,7 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, bool streamk) {
     Q.heavy_list = c->d_queue + RM_Q_HDR;
     Q.bitmaps = Q.heavy_list + 3 * (size_t)RM_HEAVY_CAP;
     Q.n_tiles = n_tiles; Q.tiles_x = tx; Q.tiles_y = ty;
+    Q.tx_magic = ((1ull << 37) + tx - 1) / tx;            // tiles per pose < 2^24, tx <= 4096: (t * magic) >> 37 == t / tx
     const bool same_shape = c->q_last_mode == P.mode && c->q_last_tiles == n_tiles && c->q_last_tx == tx && c->q_last_ty == ty;
     if (keep_history && !same_shape && c->q_last_mode != -1) {
         // the three bitmap sets were laid out for another tile count: start clean
@@ -529,6 +554,7 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, bool streamk) {
 
 int launch(rm_ctx *c, const RmParams &U, hipStream_t stream) {
     RmParams P = U;
+    frame_reciprocals(c, U.w, U.h, &P);
     // auto: the persistent queue kernel pays on the 4-slot scene, whose frames are a mass of cheap
     // tiles plus a few long ones; N-primitive scenes are uniformly expensive per tile and run
     // faster on the plain one-block-per-tile kernel (more registers free for the table walk)

@@ -86,6 +86,8 @@ struct RmQueue {
     uint32_t  use_history;   // 0: previous frame unusable (first frame, size change)
     uint32_t  cnt_cur, cnt_clr;          // counter sets: in use / cleared for the next frame
     uint32_t  hv_cur, hv_nxt, hv_clr;    // heavy sets: read / appended / cleared
+    // t / tiles_x for t < 2^24 as (t * tx_magic) >> 37, exact for tiles_x <= 4096 (tx_magic = ceil(2^37 / tiles_x))
+    uint64_t  tx_magic;
 };
 
 enum : int32_t { RM_MODE_FRAG = 0, RM_MODE_DEPTH_PERSP = 1, RM_MODE_DEPTH_ORTHO = 2 };
@@ -105,6 +107,7 @@ struct RmParams {
     float    ortho_c[4][3];    // directional pass: corners TL,TR,BR,BL
     float    ortho_fwd[3];
     int32_t  w, h;             // full frame size
+    float    inv_w, inv_h;     // RN(1/w), RN(1/h) when every pixel-centre coordinate divides exactly through rm_div_by, else 0
     int32_t  rows;             // rows rendered by this launch (compact output rows)
     int32_t  band_rows, part, n_parts;
     int32_t  mode;

@@ -91,14 +91,25 @@ struct PixelOut { uint32_t rgba; float depth; uint32_t hit; size_t oidx; };
 // and the pixel's index in the full frame (inputs) and in the compact output.
 RM_DI void rm_setup_ray(const RmParams &U, int x, int yl, int pose, V3 &ro, V3 &rd, float &depth, size_t &gidx, size_t &oidx) {
     // compact local row -> frame row (row-band shard; identity when n_parts == 1)
-    const int band = yl / U.band_rows;
-    const int y = (band * U.n_parts + U.part) * U.band_rows + (yl - band * U.band_rows);
+    int y = yl;
+    if (U.n_parts != 1) {
+        const int band = yl / U.band_rows;
+        y = (band * U.n_parts + U.part) * U.band_rows + (yl - band * U.band_rows);
+    }
     gidx = (size_t)y * (size_t)U.w + (size_t)x;
     oidx = ((size_t)pose * (size_t)U.rows + (size_t)yl) * (size_t)U.w + (size_t)x;
 
     const RmView &V = U.views ? U.views[pose] : U.view;
-    const float uu = ((float)x + 0.5f) / (float)U.w;
-    const float vv = ((float)y + 0.5f) / (float)U.h;
+    // pixel centre / frame size; the host has checked for this frame size that the 3-op exact division
+    // by a uniform divisor gives the IEEE quotient for every column and row, else inv_w = 0
+    float uu, vv;
+    if (U.inv_w != 0.0f) {
+        uu = rm_div_by((float)x + 0.5f, (float)U.w, U.inv_w);
+        vv = rm_div_by((float)y + 0.5f, (float)U.h, U.inv_h);
+    } else {
+        uu = ((float)x + 0.5f) / (float)U.w;
+        vv = ((float)y + 0.5f) / (float)U.h;
+    }
     if (U.mode == RM_MODE_DEPTH_ORTHO) {
         V3 c0 = mk3(U.ortho_c[0][0], U.ortho_c[0][1], U.ortho_c[0][2]);
         V3 c1 = mk3(U.ortho_c[1][0], U.ortho_c[1][1], U.ortho_c[1][2]);
@@ -455,9 +466,12 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
             // a tile from the heavy list is a long dependent chain that the frame cannot end before:
             // its wave gets issue priority over waves rendering cheap tiles on the same SIMD
             if (cur < n_heavy) __builtin_amdgcn_s_setprio(RM_HEAVY_PRIO); else __builtin_amdgcn_s_setprio(0);
-            const unsigned per_pose = Q.tiles_x * Q.tiles_y;
-            const unsigned pose = tile / per_pose, t2 = tile - pose * per_pose;
-            const unsigned ty = t2 / Q.tiles_x, tx = t2 - ty * Q.tiles_x;
+            unsigned pose = 0, t2 = tile;
+            if (U.n_poses != 1) {
+                const unsigned per_pose = Q.tiles_x * Q.tiles_y;
+                pose = tile / per_pose; t2 = tile - pose * per_pose;
+            }
+            const unsigned ty = (unsigned)(((unsigned long long)t2 * Q.tx_magic) >> 37), tx = t2 - ty * Q.tiles_x;
             const int x = (int)(tx * RM_TW) + (lane % RM_TW), yl = (int)(ty * RM_TH) + (lane / RM_TW);
             if (x < U.w && yl < U.rows) { po = rm_compute_pixel(U, sc, x, yl, (int)pose, t_hit, t_p, t_s); have = true; }
             c_hit += t_hit; c_p += t_p; c_s += t_s;
