@@ -291,6 +291,21 @@ RM_DI void rm_store_pixel(const RmParams &U, const PixelOut &o) {
     if (U.dst_hit) U.dst_hit[o.oidx] = (uint8_t)o.hit;
 }
 
+// wave-wide maximum, returned as a uniform value: a butterfly inside each 16-lane row with DPP
+// modifiers (no LDS crossbar, no waitcnt), then one lane per row read back and combined on the
+// scalar unit.  Must be called with all 64 lanes active.
+RM_DI unsigned rm_wave_max(unsigned v) {
+    unsigned t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);  v = v > t ? v : t;   // quad_perm [1,0,3,2]
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);  v = v > t ? v : t;   // quad_perm [2,3,0,1]
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true); v = v > t ? v : t;   // row_half_mirror
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true); v = v > t ? v : t;   // row_mirror
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+
 RM_DI unsigned rm_wave_sum(unsigned v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -501,9 +516,8 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
         // 4. framebuffer stores of `cur`, and its cost for the next frame's ordering
         if (tile != 0xffffffffu) {
             if (have) rm_store_pixel(U, po);
-            unsigned cost = t_p + t_s + (t_hit ? 7u : 0u);    // this lane's scene evaluations; wave max = the tile's length
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { unsigned v = __shfl_xor(cost, o); cost = cost > v ? cost : v; }
+            // this lane's scene evaluations; the wave maximum is the tile's length
+            const unsigned cost = rm_wave_max(t_p + t_s + (t_hit ? 7u : 0u));
 #ifdef RM_TIMELINE
             n_done++; max_cost = max_cost > cost ? max_cost : cost;
 #endif
