@@ -462,6 +462,7 @@ int check_size(rm_ctx *c, int w, int h) {
 }
 
 constexpr size_t RM_Q_HDR = 2 * RM_Q_SHARDS * RM_Q_STRIDE + 64;   // counters, then the three heavy counts on a line of their own
+constexpr uint32_t RM_STATIC_TILES_MAX = 6;      // static tiles per wave at most (see launch_queue)
 constexpr uint32_t RM_HEAVY_CAP = 8192;          // heavy-tile list entries kept per frame
 constexpr uint32_t RM_QUEUE_MAX_TILES = 160u * 1024u;   // 20 KB of LDS bitmap per block at most (4K frame = 129600 tiles)
 
@@ -541,9 +542,19 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, bool streamk) {
     unsigned blocks = want < resident ? want : resident;
     // static share: a fraction of the tiles, dealt evenly over the waves that will not start on a
     // heavy tile (at most heavy_cap of them do; the kernel uses the exact count)
-    float frac = getf(c, "_RmStaticFraction", 0.5f);
-    frac = frac < 0.0f ? 0.0f : (frac > 1.0f ? 1.0f : frac);
-    Q.static_per_wave = (uint32_t)(frac * (float)n_tiles / (float)(blocks * 4));
+    // Default (property unset or negative): three quarters of a wave's fair share but at most
+    // RM_STATIC_TILES_MAX tiles -- the static part only has to keep a wave busy until its first claim
+    // has come back; a larger fixed share leaves big frames unbalanced (4K: 264 us with 6 tiles per
+    // wave, 285 us with 24), a smaller one makes small frames wait on the counters.
+    float frac = getf(c, "_RmStaticFraction", -1.0f);
+    const float per_wave = (float)n_tiles / (float)(blocks * 4);
+    if (frac < 0.0f) {
+        const float share = 0.75f * per_wave;
+        Q.static_per_wave = (uint32_t)(share < (float)RM_STATIC_TILES_MAX ? share : (float)RM_STATIC_TILES_MAX);
+    } else {
+        frac = frac > 1.0f ? 1.0f : frac;
+        Q.static_per_wave = (uint32_t)(frac * per_wave);
+    }
     int rc = ensure_partials(c, blocks * 4, stream);
     if (rc) return rc;
     P.partials = c->d_partials;
