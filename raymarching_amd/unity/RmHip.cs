@@ -8,6 +8,11 @@ public static class RmHip
     const string Lib = "rmhip";
 
     public const int RM_OK = 0, RM_E_ARG = -1, RM_E_DEVICE = -2, RM_E_NOMEM = -3, RM_E_RANGE = -4;
+    // Primitive.type and Primitive.op bits (include/rmhip.h)
+    public const int RM_SPHERE = 0, RM_BOX = 1, RM_LINK = 2, RM_CYLINDER = 3, RM_TORUS = 4;
+    public const int RM_OP_SMAX = 1, RM_OP_NEGATE = 2;
+    // values of the _RmSceneBody property
+    public const int RM_BODY_PRIMS = 0, RM_BODY_MENGER = 1, RM_BODY_SIERPINSKI = 2, RM_BODY_MANDELBULB = 3, RM_BODY_MANDELBROT = 4;
 
     [StructLayout(LayoutKind.Sequential)]
     public struct Primitive
