@@ -248,3 +248,79 @@ def oracle_run(case: Case, O, threads: int = 0) -> dict:
         if case.kind == "shadow_persp":
             return O.shadowmap_perspective(uni, case.w, case.h, threads=threads)
         return O.shadowmap_directional(uni, case.corners, case.forward, case.w, case.h, threads=threads)
+
+
+def random_case(seed: int) -> Case:
+    """A seeded random scene for fuzzing: 1..40 primitives of all five kinds with random placement,
+    rotation, scale and op bits, or the 4-slot scene with random transforms, or a fractal body; random
+    camera on a sphere around the origin, random march uniforms, sometimes a source image / depth texture /
+    optional frag lines."""
+    rng = scenes.SplitMix64(0xF0220000 + seed)
+    u = rng.uniform
+    w, h = 24 + int(u() * 72), 16 + int(u() * 48)
+
+    def quat():
+        a = [u() * 2 - 1 for _ in range(4)]
+        n = math.sqrt(sum(x * x for x in a)) or 1.0
+        return [x / n for x in a]
+
+    kind = int(u() * 4)            # 0 table, 1 table, 2 four slots, 3 fractal
+    prims = None
+    if kind <= 1:
+        n = 1 + int(u() * 40)
+        prims = []
+        for i in range(n):
+            t = int(u() * 5)
+            params = [(0.5 + u(),), (0.5 + u(), 0.5 + u(), 0.5 + u()), (0.3 + u(), 0.2 + 0.5 * u(), 0.05 + 0.1 * u()),
+                      (0.3 + 0.5 * u(), 0.3 + 0.5 * u()), (0.4 + 0.4 * u(), 0.1 + 0.2 * u())][t]
+            ident = u() < 0.3
+            unit = u() < 0.3
+            op = 0
+            if i > 0 and u() < 0.15:
+                op |= scenes.OP_SMAX
+            if u() < 0.1:
+                op |= scenes.OP_NEGATE
+            prims.append({"type": t, "op": op, "pos": [float(F(u() * 8 - 4)), float(F(u() * 3 - 1.5)), float(F(u() * 8 - 4))],
+                          "quat": [0.0, 0.0, 0.0, 1.0] if ident else [float(F(x)) for x in quat()],
+                          "scale": [1.0, 1.0, 1.0] if unit else [float(F(0.5 + 1.5 * u())) for _ in range(3)],
+                          "color": [float(F(0.25 + 0.75 * u())) for _ in range(3)], "params": params})
+    floats = {"_MaxSteps": float(int(20 + u() * 200)), "_MaxDist": float(F(10 + u() * 40)), "_StepFactor": float(F(0.3 + u() * 0.7)),
+              "_NormalSampleScale": float(F(10 ** (-5 + 3 * u())))}
+    if kind == 3:
+        floats["_RmSceneBody"] = float(1 + int(u() * 4))
+        floats["_FractalScale"] = float(F(1.5 + u()))
+        floats["_MaxSteps"] = float(int(20 + u() * 60))
+    fx = u()
+    if fx < 0.1:
+        floats["_RmStepHeat"] = 1.0
+    elif fx < 0.2:
+        floats["_RmBounce"] = 1.0
+    elif fx < 0.3:
+        floats["_RmDebugView"] = float(1 + int(u() * 3))
+    az, el, dist = u() * 2 * math.pi, (u() - 0.5) * 1.2, 4 + u() * 8
+    pos = np.array([dist * math.cos(el) * math.sin(az), dist * math.sin(el), -dist * math.cos(el) * math.cos(az)])
+    fov = 40 + u() * 60
+    slot_rot = [quat() for _ in range(4)]
+    slot_scl = [[0.5 + 1.5 * u() for _ in range(3)] for _ in range(4)]
+    transformed = u() < 0.6
+    light = [u() * 2 - 1, u(), u() * 2 - 1, 0.0]
+    use_src, use_sd = u() < 0.3, u() < 0.3
+
+    def setup(case, mat):
+        from raymarching_amd.unity import Camera, quat_look_rotation
+        cam = Camera(transform=Transform(position=pos.astype(F), rotation=quat_look_rotation(-pos)), fieldOfView=fov,
+                     aspect=case.w / case.h, nearClipPlane=0.3, farClipPlane=1000.0)
+        ts = scenes.default_transforms()
+        if kind >= 2:
+            for t in ts:                       # bring the four slots around the origin, where the camera looks
+                t.position = (t.position * F(0.4)).astype(F)
+        if transformed:
+            for t, q, sc in zip(ts, slot_rot, slot_scl):
+                t.rotation = np.asarray(q, dtype=F)
+                t.lossyScale = np.asarray(sc, dtype=F)
+        _base(mat, case.w, case.h, camera=cam, transforms=ts)
+        mat.SetVector("_WorldSpaceLightPos0", np.asarray(light, dtype=F))
+        for k, v in floats.items():
+            mat.SetFloat(k, v)
+
+    return Case(f"random_{seed}", w, h, setup=setup, prims=prims, src=use_src, sdepth=use_sd)

@@ -256,3 +256,16 @@ def test_changing_a_uniform_changes_the_frame(torch_cuda):
         rm.OnRenderImage(None, b)
         torch.cuda.synchronize()
         assert not torch.equal(a.color, b.color)
+
+
+@pytest.mark.parametrize("kernel", ["tile", "queue"])
+@pytest.mark.parametrize("seed", range(40))
+def test_random_scenes(oracle, torch_cuda, seed, kernel):
+    """seeded random scenes (all primitive kinds, op bits, 4-slot and fractal scenes, random cameras and
+    march uniforms): bit-exact against the oracle"""
+    case = cases.random_case(seed)
+    ref = cases.oracle_run(case, oracle)
+    got = gpu_run(case, torch_cuda, kernel=KERNELS[kernel])
+    assert_frame_equal(got, ref, case.name)
+    assert got["stats"]["sum_steps_p"] == ref["stats"]["sum_steps_p"]
+    assert got["stats"]["sum_steps_s"] == ref["stats"]["sum_steps_s"]
