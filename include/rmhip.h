@@ -26,6 +26,7 @@
 #ifndef RMHIP_H
 #define RMHIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -166,6 +167,14 @@ int rm_shadowmap_directional(rm_ctx *ctx, const float corners[12], const float f
 int rm_shadowmap_directional_device(rm_ctx *ctx, const float corners[12], const float forward[3],
                                     void *d_dst_depth, void *d_dst_hit,
                                     int w, int h, void *hip_stream);
+
+/* ---- frame transport ------------------------------------------------------
+ * No counterpart in the reference (one GPU, no transport).  The blit's alpha is the constant 255
+ * (fixed4(col, 1), Assets/Raymarching.shader:214), so a finished frame that is gathered to the
+ * displaying GPU over xGMI is sent as 3 bytes per pixel: rm_pack_rgb_device before the gather,
+ * rm_unpack_rgb_device after it.  n_pixels must be a multiple of 4; asynchronous on hip_stream. */
+int rm_pack_rgb_device(rm_ctx *ctx, const void *d_rgba8, void *d_rgb8, size_t n_pixels, void *hip_stream);
+int rm_unpack_rgb_device(rm_ctx *ctx, const void *d_rgb8, void *d_rgba8, size_t n_pixels, void *hip_stream);
 
 /* ---- counters -------------------------------------------------------------
  * No counterpart in the reference (its nearest thing is the commented-out

@@ -902,6 +902,31 @@ int rm_shadowmap_directional(rm_ctx *c, const float corners[12], const float for
     RM_CATCH(c)
 }
 
+static int pack_common(rm_ctx *c, const void *in, void *out, size_t n_pixels, bool unpack, void *hip_stream) {
+    if (!c) return RM_E_ARG;
+    if (!in || !out) return fail(c, RM_E_ARG, "rm_pack_rgb_device: null buffer");
+    if (n_pixels % 4 != 0) return fail(c, RM_E_ARG, "rm_pack_rgb_device: pixel count must be a multiple of 4");
+    if (((uintptr_t)in | (uintptr_t)out) & 3u) return fail(c, RM_E_ARG, "rm_pack_rgb_device: buffers must be 4-byte aligned");
+    if (!unpack && ((uintptr_t)in & 15u)) return fail(c, RM_E_ARG, "rm_pack_rgb_device: RGBA8 buffer must be 16-byte aligned");
+    if (unpack && ((uintptr_t)out & 15u)) return fail(c, RM_E_ARG, "rm_unpack_rgb_device: RGBA8 buffer must be 16-byte aligned");
+    int rc;
+    DeviceScope ds;
+    RM_HIP(c, ds.enter(c->device));
+    if ((rc = ensure_device(c))) return rc;
+    RM_HIP(c, rm_pack_rgb(in, out, n_pixels, unpack, (hipStream_t)hip_stream));
+    return RM_OK;
+}
+int rm_pack_rgb_device(rm_ctx *c, const void *d_rgba8, void *d_rgb8, size_t n_pixels, void *hip_stream) {
+    RM_TRY
+    return pack_common(c, d_rgba8, d_rgb8, n_pixels, false, hip_stream);
+    RM_CATCH(c)
+}
+int rm_unpack_rgb_device(rm_ctx *c, const void *d_rgb8, void *d_rgba8, size_t n_pixels, void *hip_stream) {
+    RM_TRY
+    return pack_common(c, d_rgb8, d_rgba8, n_pixels, true, hip_stream);
+    RM_CATCH(c)
+}
+
 int rm_debug_counter_slots(rm_ctx *c, uint32_t *out, int max_words, int *words_per_slot, int *n_slots) {
     RM_TRY
     if (!c || !c->have_last) return fail(c, RM_E_ARG, "rm_debug_counter_slots: no blit has run");

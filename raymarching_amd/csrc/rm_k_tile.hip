@@ -23,6 +23,32 @@ __global__ __launch_bounds__(1024) void rm_reduce_stats_kernel(const unsigned *_
     if (threadIdx.x < 3) out[threadIdx.x] = s[threadIdx.x];
 }
 
+// RGBA8 -> RGB8: the alpha the blit writes is the constant 255 (fixed4(col, 1), shader:214), so a frame
+// that travels over xGMI to the displaying rank carries 3 bytes per pixel.  One thread = 4 pixels:
+// 16 bytes in, 12 bytes out, both as dwords.
+__global__ __launch_bounds__(256) void rm_pack_rgb_kernel(const uint32_t *__restrict__ rgba, uint32_t *__restrict__ rgb, size_t n_quads) {
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n_quads) return;
+    const uint4 p = reinterpret_cast<const uint4 *>(rgba)[q];
+    const uint32_t a = p.x & 0xffffffu, b = p.y & 0xffffffu, c = p.z & 0xffffffu, d = p.w & 0xffffffu;
+    uint32_t *o = rgb + q * 3;
+    o[0] = a | (b << 24);
+    o[1] = (b >> 8) | (c << 16);
+    o[2] = (c >> 16) | (d << 8);
+}
+__global__ __launch_bounds__(256) void rm_unpack_rgb_kernel(const uint32_t *__restrict__ rgb, uint32_t *__restrict__ rgba, size_t n_quads) {
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n_quads) return;
+    const uint32_t *i = rgb + q * 3;
+    const uint32_t x = i[0], y = i[1], z = i[2];
+    uint4 p;
+    p.x = (x & 0xffffffu) | 0xff000000u;
+    p.y = ((x >> 24) | ((y & 0xffffu) << 8)) | 0xff000000u;
+    p.z = ((y >> 16) | ((z & 0xffu) << 16)) | 0xff000000u;
+    p.w = (z >> 8) | 0xff000000u;
+    reinterpret_cast<uint4 *>(rgba)[q] = p;
+}
+
 template <bool ROT, int SCL>
 __global__ RM_LB void rm_tile_kernel4(const RmParams U) {
     Scene4<ROT, SCL> sc(U);
@@ -64,6 +90,16 @@ unsigned rm_tile_blocks(int w, int rows, int n_poses) {
 
 hipError_t rm_reduce_stats(const unsigned *partials, unsigned n_blocks, unsigned long long *out, hipStream_t stream) {
     hipLaunchKernelGGL(rm_reduce_stats_kernel, dim3(1), dim3(1024), 0, stream, partials, n_blocks, out);
+    return hipGetLastError();
+}
+
+hipError_t rm_pack_rgb(const void *rgba, void *rgb, size_t n_pixels, bool unpack, hipStream_t stream) {
+    const size_t n_quads = n_pixels / 4;
+    if (n_quads == 0) return hipSuccess;
+    const size_t blocks = (n_quads + 255) / 256;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    if (unpack) hipLaunchKernelGGL(rm_unpack_rgb_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const uint32_t *)rgba, (uint32_t *)rgb, n_quads);
+    else        hipLaunchKernelGGL(rm_pack_rgb_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const uint32_t *)rgba, (uint32_t *)rgb, n_quads);
     return hipGetLastError();
 }
 

@@ -16,6 +16,9 @@ unsigned rm_slot_words();
 // number of blocks (= counter slots) rm_launch_tiles uses for a launch of this shape
 unsigned rm_tile_blocks(int w, int rows, int n_poses);
 // sums n_blocks counter slots into out[0..2] (device memory)
+// RGBA8 -> RGB8 (unpack false: first argument in, second out) or RGB8 -> RGBA8 with alpha 255 (unpack true:
+// first argument is the RGB8 input, second the RGBA8 output); n_pixels must be a multiple of 4
+hipError_t rm_pack_rgb(const void *in, void *out, size_t n_pixels, bool unpack, hipStream_t stream);
 hipError_t rm_reduce_stats(const unsigned *partials, unsigned n_blocks, unsigned long long *out, hipStream_t stream);
 
 // persistent tile-queue kernel: `blocks` workgroups of 256 threads.  With blocks_per_cu != nullptr

@@ -124,6 +124,18 @@ class Material:
         self._ck(self._lib.rm_get_stats(self._ctx, C.byref(s)))
         return {"n_pixels": s.n_pixels, "n_hit": s.n_hit, "sum_steps_p": s.sum_steps_p, "sum_steps_s": s.sum_steps_s}
 
+    def pack_rgb(self, rgba, rgb, stream=None) -> None:
+        """device RGBA8 tensor [..., 4] -> device RGB8 tensor [..., 3] (frame transport: the blit's alpha is constant)"""
+        n = rgba.numel() // 4
+        self._ck(self._lib.rm_pack_rgb_device(self._ctx, _ptr(rgba), _ptr(rgb), n,
+                                              stream if stream is not None else current_stream_handle(rgba.device)))
+
+    def unpack_rgb(self, rgb, rgba, stream=None) -> None:
+        """device RGB8 tensor -> device RGBA8 tensor with alpha 255"""
+        n = rgba.numel() // 4
+        self._ck(self._lib.rm_unpack_rgb_device(self._ctx, _ptr(rgb), _ptr(rgba), n,
+                                                stream if stream is not None else current_stream_handle(rgba.device)))
+
     def set_kernel(self, variant: int) -> None:
         self._ck(self._lib.rm_set_kernel(self._ctx, int(variant)))
 

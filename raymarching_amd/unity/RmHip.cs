@@ -42,6 +42,8 @@ public static class RmHip
     [DllImport(Lib)] public static extern int rm_get_vector(IntPtr ctx, string name, [Out] float[] v4);
     [DllImport(Lib)] public static extern int rm_get_matrix(IntPtr ctx, string name, [Out] float[] m16);
     [DllImport(Lib)] public static extern int rm_has_property(IntPtr ctx, string name);
+    [DllImport(Lib)] public static extern int rm_pack_rgb_device(IntPtr ctx, IntPtr dRgba8, IntPtr dRgb8, UIntPtr nPixels, IntPtr hipStream);
+    [DllImport(Lib)] public static extern int rm_unpack_rgb_device(IntPtr ctx, IntPtr dRgb8, IntPtr dRgba8, UIntPtr nPixels, IntPtr hipStream);
     [DllImport(Lib)] public static extern int rm_set_primitives(IntPtr ctx, Primitive[] prims, int n);
 
     [DllImport(Lib)] public static extern int rm_blit(IntPtr ctx, IntPtr srcRgba8, IntPtr sceneDepth,

@@ -269,3 +269,22 @@ def test_random_scenes(oracle, torch_cuda, seed, kernel):
     assert_frame_equal(got, ref, case.name)
     assert got["stats"]["sum_steps_p"] == ref["stats"]["sum_steps_p"]
     assert got["stats"]["sum_steps_s"] == ref["stats"]["sum_steps_s"]
+
+
+def test_rgb_pack_round_trip(torch_cuda):
+    """frame transport: RGBA8 -> RGB8 -> RGBA8 (alpha 255) through the C ABI"""
+    torch = torch_cuda
+    from raymarching_amd import Material
+    g = torch.Generator(device="cpu").manual_seed(7)
+    for n in (4, 64, 1920 * 1080, 333 * 188):
+        rgba = torch.randint(0, 256, (n, 4), dtype=torch.uint8, generator=g).cuda()
+        rgb = torch.zeros((n, 3), dtype=torch.uint8, device="cuda")
+        back = torch.zeros((n, 4), dtype=torch.uint8, device="cuda")
+        with Material() as mat:
+            mat.pack_rgb(rgba, rgb)
+            mat.unpack_rgb(rgb, back)
+            torch.cuda.synchronize()
+            assert torch.equal(rgb, rgba[:, :3])
+            assert torch.equal(back[:, :3], rgba[:, :3]) and bool((back[:, 3] == 255).all())
+            with pytest.raises(RuntimeError):
+                mat.pack_rgb(rgba[:3], rgb[:3])            # not a multiple of 4 pixels
