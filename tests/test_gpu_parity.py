@@ -103,7 +103,7 @@ def test_gpu_equals_oracle(oracle, torch_cuda, name, kernel):
 @pytest.mark.parametrize("kernel,frames", [("tile", 1), ("queue", 1), ("queue", 4), ("stream", 2)])
 @pytest.mark.parametrize("name", ["default_1920x1080", "default_3840x2160"])
 def test_gpu_full_size_matches_golden_hashes(torch_cuda, name, kernel, frames):
-    """BASELINE sizes (1080p, 4K) against the oracle's committed hashes; with frames > 1 the
+    """the full benchmark sizes (1080p, 4K) against the oracle's committed hashes; with frames > 1 the
     persistent kernel orders its tile queue by the previous frame's costs, which must not
     change a single output byte"""
     case, g = cases.BY_NAME[name], GOLD[name]
