@@ -73,6 +73,7 @@ struct rm_ctx {
     uint32_t *d_queue = nullptr; size_t d_queue_cap = 0;   // counters | heavy_count | heavy_list | bitmaps
     uint32_t q_bm_cap = 0;         // capacity of one heavy bitmap in words
     uint32_t q_epoch = 0;
+    bool q_dirty = false;          // a queue launch failed: counters/lists are in an unknown rotation state
     uint32_t q_last_tiles = 0, q_last_tx = 0, q_last_ty = 0; int q_last_mode = -1;
     int n_cus = 0;
     int occ[7][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};   // resident blocks per CU by kernel variant (6 = fractal)
@@ -511,11 +512,12 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, bool streamk) {
     Q.n_tiles = n_tiles; Q.tiles_x = tx; Q.tiles_y = ty;
     Q.tx_magic = ((1ull << 37) + tx - 1) / tx;            // tiles per pose < 2^24, tx <= 4096: (t * magic) >> 37 == t / tx
     const bool same_shape = c->q_last_mode == P.mode && c->q_last_tiles == n_tiles && c->q_last_tx == tx && c->q_last_ty == ty;
-    if (keep_history && !same_shape && c->q_last_mode != -1) {
+    if (c->q_dirty || (keep_history && !same_shape && c->q_last_mode != -1)) {
         // the three bitmap sets were laid out for another tile count: start clean
         RM_HIP(c, hipStreamSynchronize(stream));
         if (c->have_last) RM_HIP(c, hipStreamSynchronize(c->last_stream));
         RM_HIP(c, hipMemset(c->d_queue, 0, c->d_queue_cap));
+        c->q_dirty = false;
     }
     Q.bitmap_words = bm_words;
     {
@@ -558,7 +560,16 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, bool streamk) {
     int rc = ensure_partials(c, blocks * 4, stream);
     if (rc) return rc;
     P.partials = c->d_partials;
-    RM_HIP(c, streamk ? rm_launch_stream(P, blocks, stream, nullptr) : rm_launch_queue(P, blocks, stream, nullptr));
+    {
+        // every frame clears the counter set and lists of a later frame: if this launch does not happen,
+        // that rotation is broken and the next launch has to start from a zeroed state
+        hipError_t le = streamk ? rm_launch_stream(P, blocks, stream, nullptr) : rm_launch_queue(P, blocks, stream, nullptr);
+        if (le != hipSuccess) {
+            c->q_dirty = true;
+            c->q_last_mode = -1;
+            return fail(c, RM_E_DEVICE, std::string("queue kernel launch: ") + hipGetErrorString(le));
+        }
+    }
     c->last_blocks = blocks * 4;
     return RM_OK;
 }
