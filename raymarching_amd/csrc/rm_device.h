@@ -65,7 +65,9 @@ static_assert(sizeof(RmView) == 64, "RmView layout");
 #define RM_TW 8
 #endif
 #define RM_TH (64 / RM_TW)
+#ifndef RM_Q_SHARDS
 #define RM_Q_SHARDS 8
+#endif
 #ifndef RM_Q_CHUNK
 #define RM_Q_CHUNK 4          // queue entries per dynamic claim
 #endif
