@@ -89,7 +89,11 @@ struct PixelOut { uint32_t rgba; float depth; uint32_t hit; size_t oidx; };
 
 // Ray of pixel (x, local row yl, pose): origin, un-normalised direction, march depth limit,
 // and the pixel's index in the full frame (inputs) and in the compact output.
-RM_DI void rm_setup_ray(const RmParams &U, int x, int yl, int pose, V3 &ro, V3 &rd, float &depth, size_t &gidx, size_t &oidx) {
+// `sv`: optional copy of U.view in LDS (ro, bl, br, tl, tr as in RmView).  The persistent kernel reads the
+// view from there once per tile: held in scalar registers across the whole tile loop, these 15 values
+// (with everything else that loop keeps) overflow the SGPR file and come back as v_readlane traffic.
+RM_DI void rm_setup_ray(const RmParams &U, int x, int yl, int pose, V3 &ro, V3 &rd, float &depth, size_t &gidx, size_t &oidx,
+                        const volatile float *sv = nullptr) {
     // compact local row -> frame row (row-band shard; identity when n_parts == 1)
     int y = yl;
     if (U.n_parts != 1) {
@@ -119,10 +123,17 @@ RM_DI void rm_setup_ray(const RmParams &U, int x, int yl, int pose, V3 &ro, V3 &
         rd = mk3(U.ortho_fwd[0], U.ortho_fwd[1], U.ortho_fwd[2]);
     } else {
         // rasteriser interpolation of vert's viewDir (cginc:26-33) to the pixel centre
-        V3 bl = mk3(V.bl[0], V.bl[1], V.bl[2]), br = mk3(V.br[0], V.br[1], V.br[2]);
-        V3 tl = mk3(V.tl[0], V.tl[1], V.tl[2]), tr = mk3(V.tr[0], V.tr[1], V.tr[2]);
-        ro = mk3(rm_vgpr(V.ro[0]), rm_vgpr(V.ro[1]), rm_vgpr(V.ro[2]));
-        rd = rm_lerp3(rm_lerp3(bl, br, uu), rm_lerp3(tl, tr, uu), vv);
+        if (sv) {
+            ro = mk3(sv[0], sv[1], sv[2]);
+            const V3 bl = mk3(sv[3], sv[4], sv[5]), br = mk3(sv[6], sv[7], sv[8]);
+            const V3 tl = mk3(sv[9], sv[10], sv[11]), tr = mk3(sv[12], sv[13], sv[14]);
+            rd = rm_lerp3(rm_lerp3(bl, br, uu), rm_lerp3(tl, tr, uu), vv);
+        } else {
+            V3 bl = mk3(V.bl[0], V.bl[1], V.bl[2]), br = mk3(V.br[0], V.br[1], V.br[2]);
+            V3 tl = mk3(V.tl[0], V.tl[1], V.tl[2]), tr = mk3(V.tr[0], V.tr[1], V.tr[2]);
+            ro = mk3(rm_vgpr(V.ro[0]), rm_vgpr(V.ro[1]), rm_vgpr(V.ro[2]));
+            rd = rm_lerp3(rm_lerp3(bl, br, uu), rm_lerp3(tl, tr, uu), vv);
+        }
     }
     depth = U.far_plane;                                          // shader:154
     if (U.mode == RM_MODE_FRAG && U.sdepth) depth = U.sdepth[gidx];
@@ -137,12 +148,12 @@ RM_DI void rm_setup_ray(const RmParams &U, int x, int yl, int pose, V3 &ro, V3 &
 // stored here: the caller decides when the framebuffer writes are issued.
 template <class S>
 RM_DI PixelOut rm_compute_pixel(const RmParams &U, const S &sc, int x, int yl, int pose,
-                                unsigned &c_hit, unsigned &c_p, unsigned &c_s) {
+                                unsigned &c_hit, unsigned &c_p, unsigned &c_s, const volatile float *sv = nullptr) {
     PixelOut out;
     V3 ro, rd;
     float depth;
     size_t gidx;
-    rm_setup_ray(U, x, yl, pose, ro, rd, depth, gidx, out.oidx);
+    rm_setup_ray(U, x, yl, pose, ro, rd, depth, gidx, out.oidx, sv);
 
     const float sf = rm_vgpr(U.step_factor);
     MarchResult r = rm_raymarch(sc, ro, rd, depth, U.n_steps, sf);
@@ -416,6 +427,13 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
         unsigned *bitmap_clr = Q.bitmaps + (size_t)Q.hv_clr * Q.bitmap_words;
         for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < Q.bitmap_words; i += gridDim.x * blockDim.x) bitmap_clr[i] = 0u;
     }
+    // the view -> LDS (see rm_setup_ray)
+    __shared__ float s_view[16];
+    if (threadIdx.x < 15) {
+        const float *v = U.view.ro;               // ro, bl, br, tl, tr are consecutive in RmView
+        s_view[threadIdx.x] = v[threadIdx.x];
+    }
+    const volatile float *sv = U.views ? nullptr : s_view;
     // this frame's heavy bitmap -> LDS
     if (Q.use_history) {
         const unsigned *bitmap_cur = Q.bitmaps + (size_t)Q.hv_cur * Q.bitmap_words;
@@ -471,6 +489,18 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
         // reserved until that long tile is done and then run as a tail behind the frame's critical
         // chain (measured: 4 tiles = 12 us at the end of the 1080p frame).  It claims when it is through.
         const bool defer_claim = cur != 0xffffffffu && cur < n_first;
+        // End game (this wave has already met an exhausted shard): look before claiming.  Every wave
+        // has to learn that every shard is empty; as atomics those are thousands of same-address
+        // operations that L2 serialises (~5 ns each, a 10-20 us tail on the frame), as loads they are
+        // served in parallel.  The wave has nothing else to do at this point, so the loads are waited for.
+        while (nxt == 0xffffffffu && dry != 0u && dry != (1u << RM_Q_SHARDS) - 1u) {
+            while (dry & (1u << shard)) shard = (shard + 1) % RM_Q_SHARDS;
+            unsigned seen = 0;
+            if (lane == 0) seen = __hip_atomic_load(&counters[shard * RM_Q_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            seen = __builtin_amdgcn_readfirstlane(seen);
+            if (chunk_first(seen, shard) < n_entries) break;       // something may be left there: claim it
+            dry |= 1u << shard;
+        }
         if (nxt == 0xffffffffu && !defer_claim && dry != (1u << RM_Q_SHARDS) - 1u) {
             while (dry & (1u << shard)) shard = (shard + 1) % RM_Q_SHARDS;
             if (lane == 0) k_raw = atomicAdd(&counters[shard * RM_Q_STRIDE], 1u);
@@ -492,7 +522,7 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
             }
             const unsigned ty = (unsigned)(((unsigned long long)t2 * Q.tx_magic) >> 37), tx = t2 - ty * Q.tiles_x;
             const int x = (int)(tx * RM_TW) + (lane % RM_TW), yl = (int)(ty * RM_TH) + (lane / RM_TW);
-            if (x < U.w && yl < U.rows) { po = rm_compute_pixel(U, sc, x, yl, (int)pose, t_hit, t_p, t_s); have = true; }
+            if (x < U.w && yl < U.rows) { po = rm_compute_pixel(U, sc, x, yl, (int)pose, t_hit, t_p, t_s, sv); have = true; }
             c_hit += t_hit; c_p += t_p; c_s += t_s;
         }
         // 3. the claim has had the whole tile to come back; read it before the stores go out
