@@ -85,6 +85,10 @@ RM_DI float rm_getshadow(const S &sc, V3 p, V3 n, V3 L, float contact, float dep
     return res;
 }
 
+// pointer into LDS with its address space spelled out: through a generic pointer the reads would be flat loads
+#define RM_LDS __attribute__((address_space(3)))
+typedef const volatile RM_LDS float *rm_lds_cfloat;
+
 struct PixelOut { uint32_t rgba; float depth; uint32_t hit; size_t oidx; };
 
 // Ray of pixel (x, local row yl, pose): origin, un-normalised direction, march depth limit,
@@ -93,7 +97,7 @@ struct PixelOut { uint32_t rgba; float depth; uint32_t hit; size_t oidx; };
 // view from there once per tile: held in scalar registers across the whole tile loop, these 15 values
 // (with everything else that loop keeps) overflow the SGPR file and come back as v_readlane traffic.
 RM_DI void rm_setup_ray(const RmParams &U, int x, int yl, int pose, V3 &ro, V3 &rd, float &depth, size_t &gidx, size_t &oidx,
-                        const volatile float *sv = nullptr) {
+                        rm_lds_cfloat sv = nullptr, bool use_sv = false) {
     // compact local row -> frame row (row-band shard; identity when n_parts == 1)
     int y = yl;
     if (U.n_parts != 1) {
@@ -123,10 +127,13 @@ RM_DI void rm_setup_ray(const RmParams &U, int x, int yl, int pose, V3 &ro, V3 &
         rd = mk3(U.ortho_fwd[0], U.ortho_fwd[1], U.ortho_fwd[2]);
     } else {
         // rasteriser interpolation of vert's viewDir (cginc:26-33) to the pixel centre
-        if (sv) {
-            ro = mk3(sv[0], sv[1], sv[2]);
-            const V3 bl = mk3(sv[3], sv[4], sv[5]), br = mk3(sv[6], sv[7], sv[8]);
-            const V3 tl = mk3(sv[9], sv[10], sv[11]), tr = mk3(sv[12], sv[13], sv[14]);
+        if (use_sv) {
+            typedef float rm_f4 __attribute__((ext_vector_type(4)));
+            const volatile RM_LDS rm_f4 *q = (const volatile RM_LDS rm_f4 *)sv;      // four ds_read_b128, one wait
+            const rm_f4 a = q[0], b = q[1], c = q[2], d = q[3];
+            ro = mk3(a.x, a.y, a.z);
+            const V3 bl = mk3(a.w, b.x, b.y), br = mk3(b.z, b.w, c.x);
+            const V3 tl = mk3(c.y, c.z, c.w), tr = mk3(d.x, d.y, d.z);
             rd = rm_lerp3(rm_lerp3(bl, br, uu), rm_lerp3(tl, tr, uu), vv);
         } else {
             V3 bl = mk3(V.bl[0], V.bl[1], V.bl[2]), br = mk3(V.br[0], V.br[1], V.br[2]);
@@ -148,12 +155,12 @@ RM_DI void rm_setup_ray(const RmParams &U, int x, int yl, int pose, V3 &ro, V3 &
 // stored here: the caller decides when the framebuffer writes are issued.
 template <class S>
 RM_DI PixelOut rm_compute_pixel(const RmParams &U, const S &sc, int x, int yl, int pose,
-                                unsigned &c_hit, unsigned &c_p, unsigned &c_s, const volatile float *sv = nullptr) {
+                                unsigned &c_hit, unsigned &c_p, unsigned &c_s, rm_lds_cfloat sv = nullptr, bool use_sv = false) {
     PixelOut out;
     V3 ro, rd;
     float depth;
     size_t gidx;
-    rm_setup_ray(U, x, yl, pose, ro, rd, depth, gidx, out.oidx, sv);
+    rm_setup_ray(U, x, yl, pose, ro, rd, depth, gidx, out.oidx, sv, use_sv);
 
     const float sf = rm_vgpr(U.step_factor);
     MarchResult r = rm_raymarch(sc, ro, rd, depth, U.n_steps, sf);
@@ -428,12 +435,13 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
         for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < Q.bitmap_words; i += gridDim.x * blockDim.x) bitmap_clr[i] = 0u;
     }
     // the view -> LDS (see rm_setup_ray)
-    __shared__ float s_view[16];
+    __shared__ __attribute__((aligned(16))) float s_view[16];
     if (threadIdx.x < 15) {
         const float *v = U.view.ro;               // ro, bl, br, tl, tr are consecutive in RmView
         s_view[threadIdx.x] = v[threadIdx.x];
     }
-    const volatile float *sv = U.views ? nullptr : s_view;
+    rm_lds_cfloat sv = (rm_lds_cfloat)s_view;
+    const bool use_sv = U.views == nullptr;
     // this frame's heavy bitmap -> LDS
     if (Q.use_history) {
         const unsigned *bitmap_cur = Q.bitmaps + (size_t)Q.hv_cur * Q.bitmap_words;
@@ -522,7 +530,7 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
             }
             const unsigned ty = (unsigned)(((unsigned long long)t2 * Q.tx_magic) >> 37), tx = t2 - ty * Q.tiles_x;
             const int x = (int)(tx * RM_TW) + (lane % RM_TW), yl = (int)(ty * RM_TH) + (lane / RM_TW);
-            if (x < U.w && yl < U.rows) { po = rm_compute_pixel(U, sc, x, yl, (int)pose, t_hit, t_p, t_s, sv); have = true; }
+            if (x < U.w && yl < U.rows) { po = rm_compute_pixel(U, sc, x, yl, (int)pose, t_hit, t_p, t_s, sv, use_sv); have = true; }
             c_hit += t_hit; c_p += t_p; c_s += t_s;
         }
         // 3. the claim has had the whole tile to come back; read it before the stores go out
