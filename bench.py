@@ -8,10 +8,11 @@ the reference's sample scene at 1920x1080 with the Raymarching.mat settings.
 A step is one full frame per GPU through the C ABI (rm_blit_device) with the
 framebuffers resident in HBM.  With N > 1 every rank renders its own frame each step
 (pose sharding, weak scaling) and the finished frames are gathered to rank 0 with RCCL
-on a side stream, overlapped with the next step's render; the timed region ends when
-every gather has landed.  Frames travel as RGB8 (the blit's alpha is the constant 255):
-a rank finishes a 1080p frame every ~105 us, i.e. 59 GB/s of RGB8 towards the root,
-which is what one xGMI link carries; RGBA8 would be 79 GB/s.  Rank 0 prints one JSON line.
+on a side stream, --gather-batch frames per collective, overlapped with the following
+renders; the timed region ends when every gather has landed.  Frames travel as RGB8
+(the blit's alpha is the constant 255): a rank
+finishes a 1080p frame every ~90 us, i.e. 70 GB/s of RGB8 towards the root, about what
+one xGMI link carries in one direction; RGBA8 would be 94 GB/s.  Rank 0 prints one JSON line.
 """
 from __future__ import annotations
 
@@ -61,6 +62,7 @@ def main() -> None:
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the RCCL gather of finished frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather-batch", type=int, default=8, help="frames per RCCL gather")
     ap.add_argument("--force-gather", action="store_true", help="developer check: run the RCCL gather path with a single rank")
     ap.add_argument("--kernel", type=int, default=0, help="kernel variant (0 = auto)")
     args = ap.parse_args()
@@ -103,15 +105,16 @@ def main() -> None:
     if gather:
         assert (w * h) % 4 == 0, "RGB8 transport packs 4 pixels at a time"
         pipe = PipelinedGather(torch.empty((h, w, 3), dtype=torch.uint8, device=dev), root=0, depth=2,
-                               single_rank_too=args.force_gather)
+                               single_rank_too=args.force_gather, batch=args.gather_batch)
     lib, ctx = mat._lib, mat.handle
 
     def step() -> None:
         mat._ck(lib.rm_blit_device(ctx, None, None, _ptr(frame), _ptr(depth), _ptr(hit), w, h, current_stream_handle(dev)))
         if pipe:
-            buf = pipe.acquire()            # stream-side wait until this buffer's previous gather is done
-            mat.pack_rgb(frame, buf)        # RGBA8 -> RGB8 on the render stream (a few us), then off to the root
-            pipe.submit(buf)
+            buf = pipe.acquire()            # slot of the current batch (stream-side wait when a new buffer is started)
+            mat.pack_rgb(frame, buf)        # RGBA8 -> RGB8 on the render stream (4 us; on the side stream it was slower:
+                                            # the extra events cost the host more than the kernel costs the GPU)
+            pipe.submit(buf)                # every gather_batch-th call: the collective, on the side stream
 
     def fence() -> None:
         if pipe:
@@ -170,7 +173,7 @@ def main() -> None:
                        "primary_rays": st["n_pixels"], "shadow_rays": st["n_hit"],
                        "scene_evals_per_frame": st["sum_steps_p"] + st["sum_steps_s"] + 7 * st["n_hit"],
                        "parallelism": ("single GPU" if world == 1 else
-                                       f"pose-sharded x{world}" + (", RCCL gather of RGB8 frames to rank 0 (overlapped)" if gather else ", no gather"))},
+                                       f"pose-sharded x{world}" + (f", RCCL gather of RGB8 frames to rank 0, {args.gather_batch} frames per collective, overlapped with rendering" if gather else ", no gather"))},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
                          "flops_per_launch": flops, "kernel_ms": kernel_ms,

@@ -91,41 +91,50 @@ def render_poses(render_pose_batch: Callable[[List[int]], torch.Tensor], n_poses
 
 
 class PipelinedGather:
-    """Gathers each step's finished frame to the root on a side stream while the next
-    step renders, with `depth` frame buffers in rotation.
+    """Gathers finished frames to the root on a side stream while later steps render, with
+    `depth` buffers of `batch` frames each in rotation.  One collective moves `batch` frames:
+    a frame of the sample scene renders in under 100 us, less than the host needs to issue a
+    collective, so gathering frame by frame would make the host the bottleneck.
 
-        g = PipelinedGather(frame_like, depth=2)
+        g = PipelinedGather(frame_like, depth=2, batch=8)
         for step in range(K):
-            buf = g.acquire()          # waits (stream-side) until its previous gather is done
+            buf = g.acquire()          # slot for this step's frame; waits (stream-side) for the
+                                       # buffer's previous gather when a new buffer is started
             render_into(buf)           # on the current stream
-            g.submit(buf)              # gather on the side stream
-        g.drain()
+            g.submit(buf)              # every `batch`-th call gathers the buffer on the side stream
+        g.drain()                      # gathers a partly filled buffer too, then joins the side stream
     """
 
-    def __init__(self, like: torch.Tensor, root: int = 0, group=None, depth: int = 2, single_rank_too: bool = False):
+    def __init__(self, like: torch.Tensor, root: int = 0, group=None, depth: int = 2, single_rank_too: bool = False,
+                 batch: int = 1):
+        assert depth >= 1 and batch >= 1
         self.root, self.group = root, group
         self.single_rank_too = single_rank_too      # run the collective even with one rank (exercises the stream logic)
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
-        self.bufs = [torch.empty_like(like) for _ in range(depth)]
+        self.batch = batch
+        shape = (batch,) + tuple(like.shape)
+        self.bufs = [torch.empty(shape, dtype=like.dtype, device=like.device) for _ in range(depth)]
         self.cuda = like.is_cuda
         self.side = torch.cuda.Stream(device=like.device) if self.cuda else None
         self.done = [None] * depth          # event: gather of bufs[i] finished
         self.recv = None
         if self.rank == root and (self.world > 1 or single_rank_too):
-            self.recv = [[torch.empty_like(like) for _ in range(self.world)] for _ in range(depth)]
-        self.i = 0
+            self.recv = [[torch.empty(shape, dtype=like.dtype, device=like.device) for _ in range(self.world)]
+                         for _ in range(depth)]
+        self.i = 0                          # frames submitted so far
+        self.last = None                    # (buffer index, frames in it) of the most recent gather
 
     def acquire(self) -> torch.Tensor:
-        k = self.i % len(self.bufs)
-        if self.cuda and self.done[k] is not None:
+        k, j = (self.i // self.batch) % len(self.bufs), self.i % self.batch
+        if j == 0 and self.cuda and self.done[k] is not None:
             torch.cuda.current_stream().wait_event(self.done[k])
-        return self.bufs[k]
+        return self.bufs[k][j]
 
-    def submit(self, buf: torch.Tensor) -> None:
-        k = self.i % len(self.bufs)
-        self.i += 1
+    def _gather(self, k: int, n_frames: int) -> None:
+        self.last = (k, n_frames)
         if self.world == 1 and not self.single_rank_too:
             return
+        buf = self.bufs[k]
         if not self.cuda:
             dist.gather(buf, self.recv[k] if self.recv else None, dst=self.root, group=self.group)
             return
@@ -138,12 +147,24 @@ class PipelinedGather:
             ev.record()
             self.done[k] = ev
 
+    def submit(self, buf: torch.Tensor) -> None:
+        k = (self.i // self.batch) % len(self.bufs)
+        self.i += 1
+        if self.i % self.batch == 0:
+            self._gather(k, self.batch)
+
     def last_gathered(self) -> Optional[List[torch.Tensor]]:
-        """root only: the frames of the most recent submit (valid after drain())"""
-        if self.recv is None:
+        """root only: per rank, the frames [n, ...] of the most recent gather (valid after drain())"""
+        if self.recv is None or self.last is None:
             return None
-        return self.recv[(self.i - 1) % len(self.bufs)]
+        k, n = self.last
+        return [t[:n] for t in self.recv[k]]
 
     def drain(self) -> None:
+        part = self.i % self.batch
+        if part:
+            # a partly filled buffer travels whole (its unused slots hold stale frames)
+            self._gather((self.i // self.batch) % len(self.bufs), part)
+            self.i += self.batch - part
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.side)

@@ -100,7 +100,19 @@ def _worker(rank, world, port, out_dir):
         pipe.drain()
         if rank == 0:
             last = pipe.last_gathered()
-            assert [int(t[0, 0]) for t in last] == [20, 21]
+            assert [int(t[0, 0, 0]) for t in last] == [20, 21]
+        # three frames per collective; the fourth and fifth frame leave with drain() as a partial batch
+        pipe = D.PipelinedGather(like, root=0, depth=2, batch=3)
+        for step in range(5):
+            buf = pipe.acquire()
+            buf.fill_(10 * step + rank)
+            pipe.submit(buf)
+            if step == 2 and rank == 0:
+                assert [[int(f[0, 0]) for f in t] for t in pipe.last_gathered()] == [[0, 10, 20], [1, 11, 21]]
+        pipe.drain()
+        if rank == 0:
+            last = pipe.last_gathered()
+            assert [[int(f[0, 0]) for f in t] for t in last] == [[30, 40], [31, 41]]
         open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
