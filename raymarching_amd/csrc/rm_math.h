@@ -52,6 +52,26 @@ RM_DI float rm_sqrt(float x) {
 #endif
 RM_DI float rm_len3(V3 a) { return rm_sqrt(rm_dot3(a, a)); }
 RM_DI float rm_len2(float x, float y) { return rm_sqrt(x * x + y * y); }
+
+// The same root with the x == 0 guard as an add instead of a clamp: t must hold RM_SQRT_TINY = 2^-126 in a
+// vector register.  x + t == x for every x >= 2^-96 (t is below a quarter ulp of x, round to nearest), so
+// the estimate and with it the result are those of rm_sqrt; at x == 0 the estimate is the finite
+// rsq(2^-126) and the result 0.  An add of two VGPRs issues in ~2.5 cycles, a min with a literal in ~4.2;
+// the primitives run six roots per scene evaluation.
+#define RM_SQRT_TINY 0x1p-126f
+#ifndef RM_SQRT_V1
+RM_DI float rm_sqrt_t(float x, float t) {
+    float y = __builtin_amdgcn_rsqf(x + t);
+    float g = x * y;
+    float h = 0.5f * y;
+    float r = __builtin_fmaf(-g, g, x);
+    return __builtin_fmaf(r, h, g);
+}
+#else
+RM_DI float rm_sqrt_t(float x, float) { return rm_sqrt(x); }
+#endif
+RM_DI float rm_len3(V3 a, float t) { return rm_sqrt_t(rm_dot3(a, a), t); }
+RM_DI float rm_len2(float x, float y, float t) { return rm_sqrt_t(x * x + y * y, t); }
 RM_DI float rm_lerp(float a, float b, float t) { return a + t * (b - a); }
 RM_DI V3 rm_lerp3(V3 a, V3 b, float t) { return mk3(rm_lerp(a.x, b.x, t), rm_lerp(a.y, b.y, t), rm_lerp(a.z, b.z, t)); }
 RM_DI float rm_clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
@@ -90,27 +110,27 @@ RM_DI V3 rm_to_local(const PT &P, V3 p) {
 }
 
 // cginc:169-171; a0 = r*.5
-template <class PT> RM_DI float rm_sphere(const PT &P, V3 p) { return rm_len3(p) - P.a0; }
+template <class PT> RM_DI float rm_sphere(const PT &P, V3 p, float t) { return rm_len3(p, t) - P.a0; }
 // cginc:173-177; a0..a2 = b*.5
-template <class PT> RM_DI float rm_box(const PT &P, V3 p) {
+template <class PT> RM_DI float rm_box(const PT &P, V3 p, float t) {
     float dx = fabsf(p.x) - P.a0, dy = fabsf(p.y) - P.a1, dz = fabsf(p.z) - P.a2;
     V3 m = mk3(fmaxf(dx, 0.0f), fmaxf(dy, 0.0f), fmaxf(dz, 0.0f));
-    return rm_len3(m) + fminf(fmaxf(dx, fmaxf(dy, dz)), 0.0f);
+    return rm_len3(m, t) + fminf(fmaxf(dx, fmaxf(dy, dz)), 0.0f);
 }
 // cginc:184-187; a0 = le, a1 = r1, a2 = r2
-template <class PT> RM_DI float rm_link(const PT &P, V3 p) {
+template <class PT> RM_DI float rm_link(const PT &P, V3 p, float t) {
     float qy = fmaxf(fabsf(p.y) - P.a0, 0.0f);
-    return rm_len2(rm_len2(p.x, qy) - P.a1, p.z) - P.a2;
+    return rm_len2(rm_len2(p.x, qy, t) - P.a1, p.z, t) - P.a2;
 }
 // cginc:189-192; a0 = h (radius), a1 = r (half height)
-template <class PT> RM_DI float rm_cylinder(const PT &P, V3 p) {
-    float dx = fabsf(rm_len2(p.x, p.z)) - P.a0;
+template <class PT> RM_DI float rm_cylinder(const PT &P, V3 p, float t) {
+    float dx = fabsf(rm_len2(p.x, p.z, t)) - P.a0;
     float dy = fabsf(p.y) - P.a1;
-    return fminf(fmaxf(dx, dy), 0.0f) + rm_len2(fmaxf(dx, 0.0f), fmaxf(dy, 0.0f));
+    return fminf(fmaxf(dx, dy), 0.0f) + rm_len2(fmaxf(dx, 0.0f), fmaxf(dy, 0.0f), t);
 }
 // cginc:179-182; a0 = t.x, a1 = t.y
-template <class PT> RM_DI float rm_torus(const PT &P, V3 p) {
-    return rm_len2(rm_len2(p.x, p.y) - P.a0, p.z) - P.a1;
+template <class PT> RM_DI float rm_torus(const PT &P, V3 p, float t) {
+    return rm_len2(rm_len2(p.x, p.y, t) - P.a0, p.z, t) - P.a1;
 }
 
 // distance lane of smin(float4 a, float4 b, .5)  (cginc:110-113)
@@ -146,15 +166,15 @@ RM_DI V4 rm_smax4(V4 a, V4 b) {
 }
 
 template <bool ROT, int SCL, class PT>
-RM_DI float rm_prim_typed(const PT &P, int type, V3 p) {
+RM_DI float rm_prim_typed(const PT &P, int type, V3 p, float t) {
     V3 l = rm_to_local<ROT, SCL>(P, p);
     float d;
     switch (type) {
-    case 0:  d = rm_sphere(P, l); break;
-    case 1:  d = rm_box(P, l); break;
-    case 2:  d = rm_link(P, l); break;
-    case 3:  d = rm_cylinder(P, l); break;
-    default: d = rm_torus(P, l); break;
+    case 0:  d = rm_sphere(P, l, t); break;
+    case 1:  d = rm_box(P, l, t); break;
+    case 2:  d = rm_link(P, l, t); break;
+    case 3:  d = rm_cylinder(P, l, t); break;
+    default: d = rm_torus(P, l, t); break;
     }
     return SCL == RM_SCL_UNIT ? d : d * P.ms;
 }
@@ -192,25 +212,27 @@ template <bool ROT, int SCL>
 struct Scene4 {
     const RmParams &U;
     PrimV P0, P1, P2, P3;
+    float tiny;
     RM_DI explicit Scene4(const RmParams &u) : U(u) {
+        tiny = rm_vgpr(RM_SQRT_TINY);
         P0 = rm_prim_to_vgpr<ROT, SCL>(u.prims4[0]);
         P1 = rm_prim_to_vgpr<ROT, SCL>(u.prims4[1]);
         P2 = rm_prim_to_vgpr<ROT, SCL>(u.prims4[2]);
         P3 = rm_prim_to_vgpr<ROT, SCL>(u.prims4[3]);
     }
     RM_DI float w(V3 p) const {
-        float o0 = rm_prim_typed<ROT, SCL>(P0, 0, p);
-        float o1 = rm_prim_typed<ROT, SCL>(P1, 1, p);
-        float o2 = rm_prim_typed<ROT, SCL>(P2, 2, p);
-        float o3 = rm_prim_typed<ROT, SCL>(P3, 3, p);
+        float o0 = rm_prim_typed<ROT, SCL>(P0, 0, p, tiny);
+        float o1 = rm_prim_typed<ROT, SCL>(P1, 1, p, tiny);
+        float o2 = rm_prim_typed<ROT, SCL>(P2, 2, p, tiny);
+        float o3 = rm_prim_typed<ROT, SCL>(P3, 3, p, tiny);
         return rm_smin_w(rm_smin_w(o0, o1), rm_smin_w(o2, o3));
     }
     RM_DI V4 full(V3 p) const {
         V4 o[4];
-        o[0].w = rm_prim_typed<ROT, SCL>(P0, 0, p);
-        o[1].w = rm_prim_typed<ROT, SCL>(P1, 1, p);
-        o[2].w = rm_prim_typed<ROT, SCL>(P2, 2, p);
-        o[3].w = rm_prim_typed<ROT, SCL>(P3, 3, p);
+        o[0].w = rm_prim_typed<ROT, SCL>(P0, 0, p, tiny);
+        o[1].w = rm_prim_typed<ROT, SCL>(P1, 1, p, tiny);
+        o[2].w = rm_prim_typed<ROT, SCL>(P2, 2, p, tiny);
+        o[3].w = rm_prim_typed<ROT, SCL>(P3, 3, p, tiny);
 #pragma unroll
         for (int i = 0; i < 4; i++) { o[i].x = U.prims4[i].cr; o[i].y = U.prims4[i].cg; o[i].z = U.prims4[i].cb; }
         return rm_smin4(rm_smin4(o[0], o[1]), rm_smin4(o[2], o[3]));
@@ -261,14 +283,15 @@ struct SceneN {
     int n;
     bool csg;              // some primitive carries an op bit
     uint32_t tail_ops;
-    RM_DI SceneN(PrimTable<LDS> t, int n_, bool csg_, uint32_t tail_ops_) : tab(t), n(n_), csg(csg_), tail_ops(tail_ops_) {}
+    float tiny;
+    RM_DI SceneN(PrimTable<LDS> t, int n_, bool csg_, uint32_t tail_ops_) : tab(t), n(n_), csg(csg_), tail_ops(tail_ops_) { tiny = rm_vgpr(RM_SQRT_TINY); }
 
     // leaf value plus what the tree needs from the record: osgn (the op of the node this leaf
     // opens as leftmost leaf of a right operand) and the type word with the cascade bits
     template <bool CSG>
     RM_DI float leaf_w(int i, V3 p, float &osgn, int &tw) const {
         const auto P = tab.get(i);
-        float d = rm_prim_typed<ROT, SCL>(P, P.type & RM_TYPE_MASK, p);
+        float d = rm_prim_typed<ROT, SCL>(P, P.type & RM_TYPE_MASK, p, tiny);
         if (CSG) { d = d * P.nsgn; osgn = P.osgn; tw = P.type; }       // x * -1 == -x exactly
         return d;
     }
@@ -276,7 +299,7 @@ struct SceneN {
     RM_DI V4 leaf4(int i, V3 p, float &osgn, int &tw) const {
         const auto P = tab.get(i);
         V4 v;
-        v.w = rm_prim_typed<ROT, SCL>(P, P.type & RM_TYPE_MASK, p);
+        v.w = rm_prim_typed<ROT, SCL>(P, P.type & RM_TYPE_MASK, p, tiny);
         if (CSG) { v.w = v.w * P.nsgn; osgn = P.osgn; tw = P.type; }
         v.x = P.cr; v.y = P.cg; v.z = P.cb;
         return v;
