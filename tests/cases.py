@@ -233,6 +233,10 @@ CASES = [
     Case("fx_bounce_view_menger_160x90", 160, 90, setup=_fx({"_RmBounce": 1.0, "_RmDebugView": 2.0}, inner=_fractal(1, True))),
     Case("shadow_persp_100x100", 100, 100, kind="shadow_persp", setup=_shadow_persp),
     Case("shadow_dir_256x144", 256, 144, kind="shadow_dir", setup=_shadow_dir),
+    # the benchmark configurations at their full sizes (hashes only; checked on the GPU)
+    Case("shadow_dir_3840x2160", 3840, 2160, kind="shadow_dir", setup=_shadow_dir, heavy=True),
+    Case("orbit_k17_7680x4320", 7680, 4320, setup=_orbit(17), heavy=True),
+    Case("stress256_1920x1080", 1920, 1080, setup=_stress, prims=scenes.stress_primitives(256), heavy=True),
 ]
 
 BY_NAME = {c.name: c for c in CASES}

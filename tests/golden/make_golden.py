@@ -7,7 +7,8 @@ was cross-checked against the independent NumPy restatement
 (oracle/numpy_restatement.py).  They guard against regressions of the oracle and
 let the GPU tests check full frames by hash.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py                 # every case
+    python tests/golden/make_golden.py NAME [NAME ...] # only these, merged into the existing files
 """
 import json
 import os
@@ -28,7 +29,14 @@ STEP_BINS = [0, 1, 2, 5, 10, 20, 40, 80, 160, 320, 640]
 
 def main():
     meta, arrays = {}, {}
+    only = sys.argv[1:]
+    if only:
+        meta = json.load(open(os.path.join(HERE, "golden.json")))["cases"]
+        with np.load(os.path.join(HERE, "subsamples.npz")) as z:
+            arrays = {k: z[k] for k in z.files}
     for c in cases.CASES:
+        if only and c.name not in only:
+            continue
         out = O_run(c)
         e = {"w": c.w, "h": c.h, "kind": c.kind, "sha_depth": sha(out["depth"]), "sha_hit": sha(out["hit"]),
              "n_hit": int(out["hit"].sum()), "sum_steps_p": int(out["stats"]["sum_steps_p"])}

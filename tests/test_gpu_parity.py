@@ -115,6 +115,22 @@ def test_gpu_full_size_matches_golden_hashes(torch_cuda, name, kernel, frames):
     assert got["stats"]["sum_steps_p"] == g["sum_steps_p"] and got["stats"]["sum_steps_s"] == g["sum_steps_s"]
 
 
+@pytest.mark.parametrize("name,kernel", [("shadow_dir_3840x2160", "tile"), ("shadow_dir_3840x2160", "queue"),
+                                         ("orbit_k17_7680x4320", "queue"), ("orbit_k17_7680x4320", "tile"),
+                                         ("stress256_1920x1080", "tile"), ("stress256_1920x1080", "queue")])
+def test_gpu_benchmark_configurations_match_golden_hashes(torch_cuda, name, kernel):
+    """the other benchmark configurations at full size against the oracle's committed hashes: the 4K
+    directional depth pass, one 8K pose of the orbit, the 256-primitive scene at 1080p with 512 steps"""
+    case, g = cases.BY_NAME[name], GOLD[name]
+    got = gpu_run(case, torch_cuda, kernel=KERNELS[kernel])
+    assert sha(got["hit"]) == g["sha_hit"]
+    assert sha(got["depth"]) == g["sha_depth"]
+    assert got["stats"]["n_hit"] == g["n_hit"] and got["stats"]["sum_steps_p"] == g["sum_steps_p"]
+    if case.kind == "frag":
+        assert sha(got["rgba"]) == g["sha_rgba"]
+        assert got["stats"]["sum_steps_s"] == g["sum_steps_s"]
+
+
 @pytest.mark.parametrize("name", ["default_src_depth_333x187", "shadow_persp_100x100", "shadow_dir_256x144", "tiny_17x3"])
 def test_host_pointer_path_equals_device_path(torch_cuda, name):
     case = cases.BY_NAME[name]
