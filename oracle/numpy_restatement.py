@@ -386,6 +386,30 @@ class Scene:
             self.fpower = 7.0 if self.body == 3 else 2.0
         self.fms = euler_matrices(props.get("_FractalRotationX", 0.0), props.get("_FractalRotationY", 0.0),
                                   props.get("_FractalRotationZ", 0.0))
+        self.dom_op = int(props.get("_RmDomainOp", 0))
+        self.dom_period = [f(v) for v in list(props.get("_RmDomainPeriod", (0, 0, 0, 0)))[:3]]
+        self.dom_size = props.get("_RmDomainSize", 1.0)
+
+    def domain(self, x, y, z):
+        """the domain operator in front of scene(): repetition (cginc:84-99), boxfold (:156-159),
+        spherefold (:161-165)"""
+        if self.dom_op == 1:
+            def shmod(v, m):
+                m = f(m)
+                hm = m * f(.5)
+                r = np.fmod(v + hm, m)                      # exact remainder with the sign of the dividend
+                return np.where(r < 0, r + m, r) - hm
+            x, y, z = (shmod(v, m) if m > 0 else v for v, m in zip((x, y, z), self.dom_period))
+        elif self.dom_op == 2:
+            b = f(self.dom_size) * f(.5)
+            x, y, z = (clamp(v, -b, b) * f(2) - v for v in (x, y, z))
+        elif self.dom_op == 3:
+            R = f(self.dom_size)
+            r = length3(x, y, z)
+            rr = r * r
+            with np.errstate(all="ignore"):
+                x, y, z = (np.where(r < R, v * R * R / rr, v) for v in (x, y, z))
+        return x, y, z
 
     def prim(self, p, x, y, z):
         """cginc:336-354: rotate(p - pos, q) / scale -> primitive -> * min(scale)"""
@@ -411,6 +435,8 @@ class Scene:
         up is the left-complete tree -- a node over n leaves has the largest power of two below n
         leaves on its left.  A node is smax (cginc:120-123) when the first leaf of its right
         operand carries the SMAX bit, smin (cginc:110-113) otherwise."""
+        if self.dom_op:
+            x, y, z = self.domain(x, y, z)
         if self.body:
             p0 = self.slot0
             lx, ly, lz = rotate_q(x - p0["pos"][0], y - p0["pos"][1], z - p0["pos"][2], p0["quat"])

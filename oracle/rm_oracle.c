@@ -430,6 +430,42 @@ static inline f4 scene_fractal(const scene_ctx *c, f3 p) {
     return o;
 }
 
+/* ---- cginc:84-99  mod / shmod.  HLSL fmod is the remainder with the sign of x and |f| < |m|; it is
+ * taken here as C's fmodf, which is that remainder exactly (the shader compiler's x - m*trunc(x/m)
+ * expansion is not bit-defined). ------------------------------------------------------------ */
+static inline float mod1(float x, float m) {
+    float r = fmodf(x, m);
+    return r < 0.0f ? r + m : r;
+}
+static inline float shmod1(float x, float m) { return mod1(x + m * .5f, m) - m * .5f; }
+/* ---- cginc:156-159  boxfold ------------------------------------------------------------------ */
+static inline f3 boxfold(f3 p, float b) {
+    b = b * .5f;
+    return v3(clamp1(p.x, -b, b) * 2.0f - p.x, clamp1(p.y, -b, b) * 2.0f - p.y, clamp1(p.z, -b, b) * 2.0f - p.z);
+}
+/* ---- cginc:161-165  spherefold --------------------------------------------------------------- */
+static inline f3 spherefold(f3 p, float R) {
+    float r = len3(p);
+    if (r < R) {
+        float rr = r * r;
+        p = v3(p.x * R * R / rr, p.y * R * R / rr, p.z * R * R / rr);
+    }
+    return p;
+}
+static inline f3 domain(const rmo_uniforms *u, f3 p) {
+    switch (u->domain_op) {
+    case 1:
+        if (u->domain_period[0] > 0.0f) p.x = shmod1(p.x, u->domain_period[0]);
+        if (u->domain_period[1] > 0.0f) p.y = shmod1(p.y, u->domain_period[1]);
+        if (u->domain_period[2] > 0.0f) p.z = shmod1(p.z, u->domain_period[2]);
+        break;
+    case 2: p = boxfold(p, u->domain_size); break;
+    case 3: p = spherefold(p, u->domain_size); break;
+    default: break;
+    }
+    return p;
+}
+
 #define RMO_MAX_PRIMS 1024
 
 /* ---- cginc:334-364  scene(p): float4(rgb, distance) ----------------------
@@ -437,6 +473,7 @@ static inline f4 scene_fractal(const scene_ctx *c, f3 p) {
  * other n the same balanced pairwise tree is built level by level in index
  * order; an odd element at the end of a level is carried up unchanged. */
 static inline f4 scene(const scene_ctx *c, f3 p) {
+    p = domain(c->u, p);
     if (c->body != RMO_BODY_PRIMS) return scene_fractal(c, p);
     f4 o[RMO_MAX_PRIMS];
     int first[RMO_MAX_PRIMS];          /* leftmost leaf under each node: its op bits choose the merge */
@@ -464,6 +501,7 @@ static inline f4 scene(const scene_ctx *c, f3 p) {
 /* distance-only evaluation: exactly scene(p).w -- the .w lane of smin4 never
  * reads rgb, so dropping the colour blend changes no bit of the result */
 static inline float scene_w(const scene_ctx *c, f3 p) {
+    p = domain(c->u, p);
     if (c->body != RMO_BODY_PRIMS) return scene_fractal(c, p).w;
     float o[RMO_MAX_PRIMS];
     int first[RMO_MAX_PRIMS];
@@ -822,6 +860,10 @@ float rmo_box(const float p[3], const float b[3]) { return sd_box(v3(p[0], p[1],
 float rmo_link(const float p[3], float le, float r1, float r2) { return sd_link(v3(p[0], p[1], p[2]), le, r1, r2); }
 float rmo_cylinder(const float p[3], float h, float r) { return sd_cylinder(v3(p[0], p[1], p[2]), h, r); }
 float rmo_torus(const float p[3], float tx, float ty) { return sd_torus(v3(p[0], p[1], p[2]), tx, ty); }
+float rmo_mod(float x, float m) { return mod1(x, m); }
+float rmo_shmod(float x, float m) { return shmod1(x, m); }
+void rmo_boxfold(const float p[3], float b, float out[3]) { f3 r = boxfold(v3(p[0], p[1], p[2]), b); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+void rmo_spherefold(const float p[3], float R, float out[3]) { f3 r = spherefold(v3(p[0], p[1], p[2]), R); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
 void rmo_rotate_q(const float v[3], const float q[4], float out[3]) {
     f4 qq = {q[0], q[1], q[2], q[3]};
     f3 r = rotate_q(v3(v[0], v[1], v[2]), qq);

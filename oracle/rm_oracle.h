@@ -79,6 +79,12 @@ typedef struct {
     int32_t fx_debug_view;       /* 1 shadow (shader:200), 2 normal*.5+.5 (:201), 3 clamp(scene(hitpoint).r*2.5-1.75,0,1) (:198) */
     int32_t fx_volumetric;       /* light integration along the ray              (shader:206-212) */
     int32_t fx_bounce;           /* one refract/reflect round                    (shader:178-187) */
+    /* domain operators the reference defines but never calls, applied to p at the top of scene():
+     * 1 repetition p = shmod(p, period) on the axes whose period is > 0 (cginc:84-99),
+     * 2 boxfold(p, size) (cginc:156-159), 3 spherefold(p, size) (cginc:161-165); 0 = none */
+    int32_t domain_op;
+    float domain_period[3];
+    float domain_size;
 } rmo_uniforms;
 
 /* scene() bodies.  PRIMS is the reference's active code (cginc:336-363).  The fractal bodies are
@@ -119,6 +125,10 @@ float rmo_box(const float p[3], const float b[3]);
 float rmo_link(const float p[3], float le, float r1, float r2);
 float rmo_cylinder(const float p[3], float h, float r);
 float rmo_torus(const float p[3], float tx, float ty);
+float rmo_mod(float x, float m);
+float rmo_shmod(float x, float m);
+void rmo_boxfold(const float p[3], float b, float out[3]);
+void rmo_spherefold(const float p[3], float R, float out[3]);
 void  rmo_rotate_q(const float v[3], const float q[4], float out[3]);
 float rmo_remap(float x, float o1, float o2, float n1, float n2);
 void  rmo_smin4(const float a[4], const float b[4], float k, float out[4]);

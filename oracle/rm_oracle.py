@@ -31,7 +31,8 @@ class RmoUniforms(C.Structure):
                 ("n_prims", C.c_int32), ("prims", C.POINTER(RmoPrim)), ("shade_miss_pixels", C.c_int32),
                 ("scene_body", C.c_int32), ("fractal_scale", C.c_float), ("fractal_rotation", C.c_float * 3),
                 ("fractal_power", C.c_float), ("fx_step_heat", C.c_int32), ("fx_debug_view", C.c_int32),
-                ("fx_volumetric", C.c_int32), ("fx_bounce", C.c_int32)]
+                ("fx_volumetric", C.c_int32), ("fx_bounce", C.c_int32),
+                ("domain_op", C.c_int32), ("domain_period", C.c_float * 3), ("domain_size", C.c_float)]
 
 
 class RmoStats(C.Structure):
@@ -74,6 +75,12 @@ def lib() -> C.CDLL:
         l.rmo_cylinder.argtypes = [FP, C.c_float, C.c_float]
         l.rmo_torus.restype = C.c_float
         l.rmo_torus.argtypes = [FP, C.c_float, C.c_float]
+        for fn in (l.rmo_mod, l.rmo_shmod):
+            fn.restype = C.c_float
+            fn.argtypes = [C.c_float, C.c_float]
+        for fn in (l.rmo_boxfold, l.rmo_spherefold):
+            fn.restype = None
+            fn.argtypes = [FP, C.c_float, FP]
         l.rmo_rotate_q.restype = None
         l.rmo_rotate_q.argtypes = [FP, FP, FP]
         l.rmo_remap.restype = C.c_float
@@ -161,6 +168,9 @@ class Uniforms:
         u.fx_debug_view = int(props.get("_RmDebugView", 0))
         u.fx_volumetric = int(props.get("_RmVolumetricLight", 0) != 0)
         u.fx_bounce = int(props.get("_RmBounce", 0) != 0)
+        u.domain_op = int(props.get("_RmDomainOp", 0))
+        u.domain_period[:] = [float(x) for x in list(props.get("_RmDomainPeriod", (0.0, 0.0, 0.0, 0.0)))[:3]]
+        u.domain_size = props.get("_RmDomainSize", 1.0)
         u.fractal_rotation[:] = [props.get("_FractalRotationX", 0.0), props.get("_FractalRotationY", 0.0),
                                  props.get("_FractalRotationZ", 0.0)]
         self.u = u
@@ -171,10 +181,10 @@ class Uniforms:
 
 
 PROP_MATRICES = ("_FrustrumCorners", "_CameraInvViewMatrix", "_Positions", "_Rotations", "_Scales")
-PROP_VECTORS = ("_WorldSpaceCameraPos", "_WorldSpaceLightPos0", "_ProjectionParams", "_BackgroundColor")
+PROP_VECTORS = ("_WorldSpaceCameraPos", "_WorldSpaceLightPos0", "_ProjectionParams", "_BackgroundColor", "_RmDomainPeriod")
 PROP_FLOATS = ("_MaxSteps", "_MaxDist", "_StepFactor", "_ContactThreshold", "_NormalSampleScale",
                "_FractalScale", "_FractalRotationX", "_FractalRotationY", "_FractalRotationZ", "_RmSceneBody", "_RmFractalPower",
-               "_RmStepHeat", "_RmDebugView", "_RmVolumetricLight", "_RmBounce")
+               "_RmStepHeat", "_RmDebugView", "_RmVolumetricLight", "_RmBounce", "_RmDomainOp", "_RmDomainSize")
 
 
 def props_from_material(mat) -> dict:

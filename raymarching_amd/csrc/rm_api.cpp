@@ -169,6 +169,9 @@ void load_defaults(rm_ctx *c) {
     c->floats["_RmDebugView"] = 0.0f;
     c->floats["_RmVolumetricLight"] = 0.0f;
     c->floats["_RmBounce"] = 0.0f;
+    c->floats["_RmDomainOp"] = 0.0f;
+    c->floats["_RmDomainSize"] = 1.0f;              // default b of boxfold (cginc:156) and R of spherefold (cginc:161)
+    c->vectors["_RmDomainPeriod"] = {0, 0, 0, 0};
     c->floats["_Glossiness"] = 0.2f;
     c->floats["_MaxDist"] = 50.0f;
     c->floats["_MaxSteps"] = 400.0f;
@@ -432,6 +435,11 @@ int build_params(rm_ctx *c, RmParams *U, hipStream_t stream) {
                   (getf(c, "_RmBounce", 0.0f) != 0.0f ? RM_FX_BOUNCE : 0u);
     U->fx_view = (int32_t)getf(c, "_RmDebugView", 0.0f);
     if (U->fx_view < 0 || U->fx_view > 3) return fail(c, RM_E_ARG, "_RmDebugView must be 0..3");
+    U->dom_op = (int32_t)getf(c, "_RmDomainOp", 0.0f);
+    if (U->dom_op < RM_DOM_NONE || U->dom_op > RM_DOM_SPHEREFOLD) return fail(c, RM_E_ARG, "_RmDomainOp must be 0..3");
+    const vec4 period = getv(c, "_RmDomainPeriod");
+    for (int i = 0; i < 3; i++) U->dom_period[i] = period[i];
+    U->dom_size = getf(c, "_RmDomainSize", 1.0f);
     return RM_OK;
 }
 
@@ -584,6 +592,7 @@ int launch(rm_ctx *c, const RmParams &U, hipStream_t stream) {
     int kernel = c->kernel != RM_KERNEL_AUTO ? c->kernel : ((U.n_prims > 0 || U.body != RM_BODY_PRIMS) ? RM_KERNEL_TILE : RM_KERNEL_QUEUE);
     if (U.body != RM_BODY_PRIMS && kernel == RM_KERNEL_STREAM) kernel = RM_KERNEL_QUEUE;      // no stream kernel for the fractal bodies
     if (U.mode == RM_MODE_FRAG && (U.fx_flags != 0 || U.fx_view != 0)) kernel = RM_KERNEL_TILE;   // the optional frag lines exist in the tile kernels only
+    if (U.dom_op != RM_DOM_NONE) kernel = RM_KERNEL_TILE;                                          // and so do the domain operators
     if (kernel == RM_KERNEL_TILE) {
         unsigned n_blocks = rm_tile_blocks(U.w, U.rows, U.n_poses);
         int rc = ensure_partials(c, n_blocks, stream);

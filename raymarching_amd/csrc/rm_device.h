@@ -139,7 +139,14 @@ struct RmParams {
     // lines of frag the reference keeps commented out (0 = the shader as it stands); tile kernels only
     uint32_t fx_flags;         // RM_FX_*
     int32_t  fx_view;          // 1 shadow (shader:200), 2 normal*.5+.5 (:201), 3 clamp(scene(hitpoint).r*2.5-1.75,0,1) (:198)
+    // domain operator applied to p at the top of scene() (functions the reference defines and never calls);
+    // tile kernels with the optional lines only
+    int32_t  dom_op;           // RM_DOM_*
+    float    dom_period[3];    // m of shmod (cginc:94-99) per axis; <= 0: axis left alone
+    float    dom_size;         // b of boxfold (cginc:156) / R of spherefold (cginc:161)
 };
+
+enum : int32_t { RM_DOM_NONE = 0, RM_DOM_REPEAT = 1, RM_DOM_BOXFOLD = 2, RM_DOM_SPHEREFOLD = 3 };
 
 enum : uint32_t { RM_FX_STEP_HEAT = 1, RM_FX_VOLUMETRIC = 2, RM_FX_BOUNCE = 4 };
 

@@ -1,4 +1,5 @@
-// rm_k_tile_fx.hip -- the tile kernels with frag's optional lines (rm_compute_pixel_fx).
+// rm_k_tile_fx.hip -- the tile kernels with frag's optional lines (rm_compute_pixel_fx) and the domain
+// operators in front of scene() (SceneDom).
 #include "rm_kernels_common.h"
 
 namespace {
@@ -6,7 +7,7 @@ namespace {
 template <bool ROT, int SCL>
 __global__ RM_LB void rm_tile_kernel4_fx(const RmParams U) {
     Scene4<ROT, SCL> sc(U);
-    rm_pixel<true>(U, sc);
+    rm_pixel<true>(U, SceneDom<Scene4<ROT, SCL>>(sc, U));
 }
 
 template <bool ROT, int SCL>
@@ -14,17 +15,17 @@ __global__ RM_LB void rm_tile_kernelN_fx(const RmParams U) {
     if (U.lds_prims) {
         PrimTable<true> t; t.T = rm_stage_table(U, 0);
         SceneN<ROT, SCL, true> sc(t, U.n_prims, (U.scene_flags & RM_SF_CSG) != 0, U.tail_ops);
-        rm_pixel<true>(U, sc);
+        rm_pixel<true>(U, SceneDom<SceneN<ROT, SCL, true>>(sc, U));
     } else {
         PrimTable<false> t; t.T = U.prim_table;
         SceneN<ROT, SCL, false> sc(t, U.n_prims, (U.scene_flags & RM_SF_CSG) != 0, U.tail_ops);
-        rm_pixel<true>(U, sc);
+        rm_pixel<true>(U, SceneDom<SceneN<ROT, SCL, false>>(sc, U));
     }
 }
 
 __global__ RM_LB void rm_tile_kernelF_fx(const RmParams U) {
     SceneF sc(U);
-    rm_pixel<true>(U, sc);
+    rm_pixel<true>(U, SceneDom<SceneF>(sc, U));
 }
 template <bool ROT, int SCL>
 hipError_t launch_variant_fx(const RmParams &U, dim3 grid, hipStream_t stream) {

@@ -643,6 +643,47 @@ struct SceneF {
     RM_DI V4 full(V3 p) const { return eval<true>(p); }
 };
 
+// Domain operators in front of any scene: the functions the reference defines for this and never calls.
+//   repeat      p = shmod(p, m) on the axes with m > 0; mod = fmod made non-negative (cginc:84-99).  fmodf is
+//               the exact remainder on both the host and the GPU, so CPU and GPU results agree bit for bit
+//   boxfold     b *= .5; p = clamp(p, -b, b) * 2.0 - p                 (cginc:156-159)
+//   spherefold  r = length(p); if (r < R) p = p * R * R / (r * r)      (cginc:161-165)
+// The operator is wave-uniform.  Compiled into the kernels with the optional lines only.
+template <class S>
+struct SceneDom {
+    const S &in;
+    int op;
+    float mx, my, mz, size;
+    RM_DI SceneDom(const S &s, const RmParams &u) : in(s), op(u.dom_op), mx(u.dom_period[0]), my(u.dom_period[1]),
+                                                   mz(u.dom_period[2]), size(u.dom_size) {}
+    RM_DI static float shmod(float x, float m) {
+        const float hm = m * .5f;
+        float r = fmodf(x + hm, m);
+        r = r < 0.0f ? r + m : r;
+        return r - hm;
+    }
+    RM_DI static float fold1(float x, float b) { return fminf(fmaxf(x, -b), b) * 2.0f - x; }
+    RM_DI V3 apply(V3 p) const {
+        if (op == RM_DOM_REPEAT) {
+            if (mx > 0.0f) p.x = shmod(p.x, mx);
+            if (my > 0.0f) p.y = shmod(p.y, my);
+            if (mz > 0.0f) p.z = shmod(p.z, mz);
+        } else if (op == RM_DOM_BOXFOLD) {
+            const float b = size * .5f;
+            p = mk3(fold1(p.x, b), fold1(p.y, b), fold1(p.z, b));
+        } else if (op == RM_DOM_SPHEREFOLD) {
+            const float r = sqrtf(rm_dot3(p, p));
+            if (r < size) {
+                const float rr = r * r;
+                p = mk3(p.x * size * size / rr, p.y * size * size / rr, p.z * size * size / rr);
+            }
+        }
+        return p;
+    }
+    RM_DI float w(V3 p) const { return in.w(apply(p)); }
+    RM_DI V4 full(V3 p) const { return in.full(apply(p)); }
+};
+
 RM_DI uint32_t rm_unorm8(float x) {
     x = fminf(fmaxf(x, 0.0f), 1.0f);           // saturate; a NaN becomes 0
     return (uint32_t)floorf(x * 255.0f + 0.5f);

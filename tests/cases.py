@@ -148,6 +148,21 @@ def _fx(floats, inner=None, bg=None):
     return f
 
 
+def _domain(op, period=(0, 0, 0), size=1.0, inner=None, floats=None):
+    """a scene seen through one of the domain operators (cginc:84-99, 156-165)"""
+    def f(case, mat):
+        if inner:
+            inner(case, mat)
+        else:
+            _base(mat, case.w, case.h)
+        mat.SetFloat("_RmDomainOp", float(op))
+        mat.SetVector("_RmDomainPeriod", np.asarray(list(period) + [0.0], dtype=F))
+        mat.SetFloat("_RmDomainSize", float(size))
+        for k, v in (floats or {}).items():
+            mat.SetFloat(k, v)
+    return f
+
+
 def _shadow_persp(case, mat):
     _base(mat, case.w, case.h)
     sm = ShadowMap(scenes.shadow_camera(case.w, case.h), mat)
@@ -233,6 +248,16 @@ CASES = [
     Case("fx_bounce_view_menger_160x90", 160, 90, setup=_fx({"_RmBounce": 1.0, "_RmDebugView": 2.0}, inner=_fractal(1, True))),
     Case("shadow_persp_100x100", 100, 100, kind="shadow_persp", setup=_shadow_persp),
     Case("shadow_dir_256x144", 256, 144, kind="shadow_dir", setup=_shadow_dir),
+    # domain operators in front of scene()
+    Case("dom_repeat_xz_320x180", 320, 180, setup=_domain(1, period=(9.0, 0.0, 7.5))),
+    Case("dom_repeat_xyz_stress13_160x90", 160, 90, setup=_domain(1, period=(8.0, 40.0, 8.0), inner=_stress),
+         prims=scenes.stress_primitives(13, seed=0x5EED000D)),
+    Case("dom_repeat_menger_bounce_160x90", 160, 90, setup=_domain(1, period=(3.0, 3.0, 3.0), inner=_fractal(1, True),
+                                                                    floats={"_RmBounce": 1.0})),
+    Case("dom_boxfold_240x135", 240, 135, setup=_domain(2, size=6.0)),
+    Case("dom_boxfold_sierpinski_160x90", 160, 90, setup=_domain(2, size=2.5, inner=_fractal(2, True))),
+    Case("dom_spherefold_240x135", 240, 135, setup=_domain(3, size=3.0)),
+    Case("dom_repeat_shadow_dir_128x72", 128, 72, kind="shadow_dir", setup=lambda c, m: (_shadow_dir(c, m), _domain(1, period=(6.0, 0.0, 6.0), inner=lambda c2, m2: None)(c, m))),
     # the benchmark configurations at their full sizes (hashes only; checked on the GPU)
     Case("shadow_dir_3840x2160", 3840, 2160, kind="shadow_dir", setup=_shadow_dir, heavy=True),
     Case("orbit_k17_7680x4320", 7680, 4320, setup=_orbit(17), heavy=True),
@@ -258,7 +283,7 @@ def random_case(seed: int) -> Case:
     """A seeded random scene for fuzzing: 1..40 primitives of all five kinds with random placement,
     rotation, scale and op bits, or the 4-slot scene with random transforms, or a fractal body; random
     camera on a sphere around the origin, random march uniforms, sometimes a source image / depth texture /
-    optional frag lines."""
+    optional frag lines / a domain operator."""
     rng = scenes.SplitMix64(0xF0220000 + seed)
     u = rng.uniform
     w, h = 24 + int(u() * 72), 16 + int(u() * 48)
@@ -309,6 +334,13 @@ def random_case(seed: int) -> Case:
     transformed = u() < 0.6
     light = [u() * 2 - 1, u(), u() * 2 - 1, 0.0]
     use_src, use_sd = u() < 0.3, u() < 0.3
+    dom, dom_op, dom_period, dom_size = u(), 0, [0.0, 0.0, 0.0], 1.0
+    if dom < 0.12:
+        dom_op, dom_period = 1, [float(F(3 + 6 * u())) if u() < 0.7 else 0.0 for _ in range(3)]
+    elif dom < 0.18:
+        dom_op, dom_size = 2, float(F(2 + 6 * u()))
+    elif dom < 0.24:
+        dom_op, dom_size = 3, float(F(1 + 3 * u()))
 
     def setup(case, mat):
         from raymarching_amd.unity import Camera, quat_look_rotation
@@ -326,5 +358,9 @@ def random_case(seed: int) -> Case:
         mat.SetVector("_WorldSpaceLightPos0", np.asarray(light, dtype=F))
         for k, v in floats.items():
             mat.SetFloat(k, v)
+        if dom_op:
+            mat.SetFloat("_RmDomainOp", float(dom_op))
+            mat.SetVector("_RmDomainPeriod", np.asarray(dom_period + [0.0], dtype=F))
+            mat.SetFloat("_RmDomainSize", dom_size)
 
     return Case(f"random_{seed}", w, h, setup=setup, prims=prims, src=use_src, sdepth=use_sd)

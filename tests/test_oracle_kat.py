@@ -53,6 +53,31 @@ def test_torus(oracle):                        # cginc:179-182
     assert l.rmo_torus(p3(0, 0, 0), .5, .25) == 0.25
 
 
+def test_mod_and_shmod(oracle):                # cginc:84-99
+    l = oracle.lib()
+    assert l.rmo_mod(5.5, 2.0) == 1.5
+    assert l.rmo_mod(-0.5, 2.0) == 1.5           # made non-negative
+    assert l.rmo_mod(-4.0, 2.0) == 0.0
+    assert l.rmo_shmod(0.25, 2.0) == 0.25        # inside the centred cell: unchanged
+    assert l.rmo_shmod(1.25, 2.0) == -0.75       # wraps to [-m/2, m/2)
+    assert l.rmo_shmod(-1.0, 2.0) == -1.0
+    assert l.rmo_shmod(1.0, 2.0) == -1.0
+    assert l.rmo_shmod(7.0, 2.0) == -1.0 and l.rmo_shmod(8.5, 2.0) == 0.5
+
+
+def test_folds(oracle):                        # cginc:156-165
+    l = oracle.lib()
+    out = f32([0, 0, 0])
+    l.rmo_boxfold(p3(0.25, -0.75, 2.0), 1.0, fp(out))      # b = .5: inside unchanged, outside mirrored
+    assert out.tolist() == [0.25, -0.25, -1.0]
+    l.rmo_spherefold(p3(0.5, 0.0, 0.0), 1.0, fp(out))      # inversion in the unit sphere
+    assert out.tolist() == [2.0, 0.0, 0.0]
+    l.rmo_spherefold(p3(0.0, 3.0, 0.0), 2.0, fp(out))      # outside R: unchanged
+    assert out.tolist() == [0.0, 3.0, 0.0]
+    l.rmo_spherefold(p3(0.0, 0.0, -1.0), 2.0, fp(out))     # p * R * R / (r * r)
+    assert out.tolist() == [0.0, 0.0, -4.0]
+
+
 def test_smin(oracle):                         # cginc:110-113
     l = oracle.lib()
     out = f32([0, 0, 0, 0])
