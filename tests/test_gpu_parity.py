@@ -214,6 +214,37 @@ def test_pose_batch_equals_single_blits(oracle, torch_cuda):
     assert np.array_equal(c[2].cpu().numpy(), ref["rgba"])
 
 
+def test_pose_batch_at_full_size(torch_cuda):
+    """three 7680x4320 orbit poses in one rm_blit_poses_device call; the middle one is pose 17, whose
+    hashes are committed"""
+    torch = torch_cuda
+    from raymarching_amd import Material, Raymarching, scenes
+    from raymarching_amd.material import _fp, _ptr, current_stream_handle
+    w, h, ks = 7680, 4320, [9, 17, 25]
+    g = GOLD["orbit_k17_7680x4320"]
+    with Material() as mat:
+        mat.SetVector("_WorldSpaceLightPos0", scenes.WORLD_SPACE_LIGHT_POS0)
+        cams = [Raymarching(scenes.orbit_camera(k, 64, w, h), mat, scenes.default_transforms()) for k in ks]
+        cams[0].bind()
+        fcs = np.ascontiguousarray(np.stack([r.GetFrustumCorners().m for r in cams]), dtype=np.float32)
+        c2ws = np.ascontiguousarray(np.stack([r.cam.cameraToWorldMatrix.m for r in cams]), dtype=np.float32)
+        pos = np.ascontiguousarray(np.stack([r.cam.transform.position for r in cams]), dtype=np.float32)
+        n = len(ks)
+        color = torch.zeros((n, h, w, 4), dtype=torch.uint8, device="cuda:0")
+        depth = torch.zeros((n, h, w), dtype=torch.float32, device="cuda:0")
+        hit = torch.zeros((n, h, w), dtype=torch.uint8, device="cuda:0")
+        for _ in range(2):                       # the second frame runs with the first one's tile costs
+            mat._ck(mat._lib.rm_blit_poses_device(mat.handle, n, _fp(fcs), _fp(c2ws), _fp(pos), _ptr(color), _ptr(depth),
+                                                  _ptr(hit), w, h, current_stream_handle("cuda:0")))
+        torch.cuda.synchronize()
+        st = mat.stats()
+        assert st["n_pixels"] == n * w * h
+        assert sha(color[1].cpu().numpy()) == g["sha_rgba"]
+        assert sha(depth[1].cpu().numpy()) == g["sha_depth"]
+        assert sha(hit[1].cpu().numpy()) == g["sha_hit"]
+        assert int(hit[1].sum().item()) == g["n_hit"]
+
+
 @pytest.mark.parametrize("name", ["stress256_320x180", "orbit_k23_480x270", "shadow_dir_256x144"])
 def test_tile_history_does_not_change_output(oracle, torch_cuda, name):
     """3rd consecutive frame (heavy tiles first) == 1st frame == oracle, also with a very low threshold"""
