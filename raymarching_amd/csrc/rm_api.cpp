@@ -589,7 +589,10 @@ int launch(rm_ctx *c, const RmParams &U, hipStream_t stream) {
     // tiles plus a few long ones; N-primitive scenes are uniformly expensive per tile and run
     // faster on the plain one-block-per-tile kernel (more registers free for the table walk)
     // (the fractal bodies are uniformly expensive too: measured 1.18 ms tile vs 1.57 ms queue at 1080p)
-    int kernel = c->kernel != RM_KERNEL_AUTO ? c->kernel : ((U.n_prims > 0 || U.body != RM_BODY_PRIMS) ? RM_KERNEL_TILE : RM_KERNEL_QUEUE);
+    // (the depth passes have no shadow march and hence no long tiles either: 4K directional pass 276 us tile vs
+    // 311 us queue; keeping them off the persistent kernel also keeps their tile costs out of the frag pass's history)
+    int kernel = c->kernel != RM_KERNEL_AUTO ? c->kernel
+               : ((U.n_prims > 0 || U.body != RM_BODY_PRIMS || U.mode != RM_MODE_FRAG) ? RM_KERNEL_TILE : RM_KERNEL_QUEUE);
     if (U.body != RM_BODY_PRIMS && kernel == RM_KERNEL_STREAM) kernel = RM_KERNEL_QUEUE;      // no stream kernel for the fractal bodies
     if (U.mode == RM_MODE_FRAG && (U.fx_flags != 0 || U.fx_view != 0)) kernel = RM_KERNEL_TILE;   // the optional frag lines exist in the tile kernels only
     if (U.dom_op != RM_DOM_NONE) kernel = RM_KERNEL_TILE;                                          // and so do the domain operators

@@ -174,7 +174,7 @@ def _shadow_persp(case, mat):
 
 def _shadow_dir(case, mat):
     _base(mat, case.w, case.h)
-    # the ShadowMap object's transform reused as the rectangle, as the survey's config 3 does:
+    # the ShadowMap object's transform reused as the rectangle (the 4K depth-pass benchmark configuration):
     # a 14 x 8 rectangle above and behind the objects, looking back at them
     t = Transform(position=vec3(-3, 3, 9), rotation=scenes.shadow_camera().transform.rotation, lossyScale=vec3(14, 8, 1))
     smd = ShadowMapDirectional(t, mat)
