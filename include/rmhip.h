@@ -188,6 +188,13 @@ int rm_debug_counter_slots(rm_ctx *ctx, uint32_t *out, int max_words, int *words
 /* kernel variant for the next blits: 0 = auto */
 int rm_set_kernel(rm_ctx *ctx, int variant);
 
+/* Unity's native-plugin loader calls these two, if a plugin exports them, when it loads and unloads the
+ * library (Unity's IUnityInterface.h).  The scripts this library replaces (Assets/Raymarching.cs,
+ * Assets/ShadowMap.cs, Assets/ShadowMapDirectional.cs) use nothing of the interface registry, so both do
+ * nothing; they are exported so that the library behaves as a regular plugin under Assets/Plugins. */
+void UnityPluginLoad(void *unity_interfaces);
+void UnityPluginUnload(void);
+
 #ifdef __cplusplus
 }
 #endif

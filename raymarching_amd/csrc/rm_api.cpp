@@ -621,6 +621,9 @@ extern "C" {
 
 const char *rm_version(void) { return "rmhip 0.1 (gfx950)"; }
 
+void UnityPluginLoad(void *) {}
+void UnityPluginUnload(void) {}
+
 rm_ctx *rm_create(int hip_device) {
     rm_ctx *c = nullptr;
     try {

@@ -43,6 +43,8 @@ SYMBOLS = [
     ("rm_destroy", None, [_P]),
     ("rm_last_error", C.c_char_p, [_P]),
     ("rm_version", C.c_char_p, []),
+    ("UnityPluginLoad", None, [_P]),
+    ("UnityPluginUnload", None, []),
     ("rm_set_float", C.c_int, [_P, C.c_char_p, C.c_float]),
     ("rm_set_int", C.c_int, [_P, C.c_char_p, C.c_int]),
     ("rm_set_vector", C.c_int, [_P, C.c_char_p, _FP]),

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_functions():
     src = open(os.path.join(ROOT, "include", "rmhip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(rm_[a-z_0-9]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(rm_[a-z_0-9]+|UnityPlugin[A-Za-z]+)\s*\(", src)))
 
 
 def test_every_declared_symbol_is_exported_and_bound():
