@@ -306,7 +306,7 @@ def test_changing_a_uniform_changes_the_frame(torch_cuda):
 
 
 @pytest.mark.parametrize("kernel", ["tile", "queue"])
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(72))
 def test_random_scenes(oracle, torch_cuda, seed, kernel):
     """seeded random scenes (all primitive kinds, op bits, 4-slot and fractal scenes, random cameras and
     march uniforms): bit-exact against the oracle"""
