@@ -177,6 +177,7 @@ def main() -> None:
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
                          "flops_per_launch": flops, "kernel_ms": kernel_ms,
+                         "sdf_evals_per_s": (st["sum_steps_p"] + st["sum_steps_s"] + 7 * st["n_hit"]) / (kernel_ms * 1e-3),
                          "framebuffer_GBps": (9.0 * st["n_pixels"]) / (kernel_ms * 1e-3) / 1e9},
         }
         if world == 1 and not args.no_cpu_baseline:
