@@ -159,6 +159,12 @@ def main() -> None:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        spath = os.path.join(ROOT, "profiles", "traffic_by_size.json")
+        if traffic is None and os.path.exists(spath):
+            try:
+                traffic = json.load(open(spath)).get(f"{w}x{h}", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
         out = {
             "metric": "Mrays/s (primary+shadow)",
             "value": rays_per_step * args.steps / elapsed / 1e6,

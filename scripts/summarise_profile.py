@@ -82,6 +82,12 @@ def main():
         json.dump({"width": w, "height": h, "kernel": main_kernel, "hbm_bytes_per_launch": js["hbm_bytes_per_launch"],
                    "source": os.path.basename(dst) + "_summary.json"},
                   open(os.path.join(os.path.dirname(dst) or ".", "traffic_latest.json"), "w"), indent=1)
+        # one entry per frame size, so that bench.py can quote the counters for whichever size it runs
+        by_size_path = os.path.join(os.path.dirname(dst) or ".", "traffic_by_size.json")
+        by_size = json.load(open(by_size_path)) if os.path.exists(by_size_path) else {}
+        by_size[f"{w}x{h}"] = {"kernel": main_kernel, "hbm_bytes_per_launch": js["hbm_bytes_per_launch"],
+                               "source": os.path.basename(dst) + "_summary.json"}
+        json.dump(by_size, open(by_size_path, "w"), indent=1, sort_keys=True)
     print("\n".join(lines))
 
 
