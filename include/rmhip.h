@@ -130,6 +130,18 @@ int rm_blit_device(rm_ctx *ctx, const void *d_src_rgba8, const void *d_scene_dep
                    void *d_dst_rgba8, void *d_dst_depth, void *d_dst_hit,
                    int w, int h, void *hip_stream);
 
+/* The same blits with one more output: a per-pixel step-count plane, two uint16 per pixel (a 32-bit word:
+ * low half = scene() evaluations of the primary march, i.e. what ray.steps counts at
+ * Assets/Raymarching.cginc:37,387 plus the evaluation the loop broke on; high half = evaluations of the
+ * soft-shadow march, 0 for miss pixels).  Replaces: the reference's only debug aid for the march, the
+ * commented-out heat map `col += r.steps / 100 * _StepFactor` (Assets/Raymarching.shader:203), as data
+ * instead of colour.  The frame sums of both halves are what rm_get_stats returns.  steps may be NULL. */
+int rm_blit_steps(rm_ctx *ctx, const uint8_t *src_rgba8, const float *scene_depth,
+                  uint8_t *dst_rgba8, float *dst_depth, uint8_t *dst_hit, uint16_t *dst_steps, int w, int h);
+int rm_blit_steps_device(rm_ctx *ctx, const void *d_src_rgba8, const void *d_scene_depth,
+                         void *d_dst_rgba8, void *d_dst_depth, void *d_dst_hit, void *d_dst_steps,
+                         int w, int h, void *hip_stream);
+
 /* Row-band shard of one frame for multi-GPU rendering: renders the rows y of the
  * w x h frame with (y / band_rows) % n_parts == part into COMPACT buffers that
  * hold only those rows, in increasing y.  rm_band_rows() gives their count.

@@ -49,9 +49,31 @@ typedef std::array<float, 16> mat4;
 
 }  // namespace
 
+// Host-side state of the persistent kernel's tile queue together with the device buffer it describes.
+// The buffer is either owned by a context (grown on demand) or a slice of the per-device static scratch
+// array (fixed capacity, shared by every context on that GPU).
+struct QueueState {
+    uint32_t *buf = nullptr; size_t cap_bytes = 0;   // counters | heavy_count | heavy_list | bitmaps
+    uint32_t bm_cap = 0;           // capacity of one heavy bitmap in words
+    uint32_t epoch = 0;
+    bool zeroed = false;           // the buffer holds zeros and no launch has used it since
+    bool dirty = false;            // a queue launch failed: counters/lists are in an unknown rotation state
+    bool history = false;          // the last launch appended tile costs for a frame of the shape below
+    uint32_t last_tiles = 0, last_tx = 0, last_ty = 0; int last_mode = -1;
+};
+
+// Device memory a launch works in beyond the caller's images: queue state, counter slots, reduced counters.
+struct WorkMem {
+    QueueState *q = nullptr;
+    uint32_t **partials = nullptr; size_t *partials_cap = nullptr;   // bytes
+    unsigned long long *stats = nullptr;
+    bool fixed = false;            // static scratch: nothing can grow, sizes beyond capacity are refused
+};
+
 struct rm_ctx {
     int device = 0;
-    bool dev_ready = false;
+    bool dev_ready = false;        // stream, event and d_stats exist
+    bool props_ready = false;      // n_cus / lds_per_block are known
     std::string err;
     std::map<std::string, float> floats;
     std::map<std::string, vec4> vectors;
@@ -60,29 +82,30 @@ struct rm_ctx {
     bool prims_dirty = false;
     int kernel = RM_KERNEL_AUTO;
 
-    hipStream_t stream = nullptr;           // used by the host-pointer entry points
+    hipStream_t stream = nullptr;           // used by the host-pointer entry points and by rm_get_stats
+    hipEvent_t ev_last = nullptr;           // recorded behind every launch of the allocating entry points
+    bool ev_recorded = false;
     unsigned long long *d_stats = nullptr;  // reduced counters of the last launch (filled by rm_get_stats)
     uint32_t *d_partials = nullptr; size_t d_partials_cap = 0;   // per-block counter slots of the last launch
-    unsigned last_blocks = 0;
     RmPrimDev *d_prims = nullptr;  size_t d_prims_cap = 0;
     RmView *d_views = nullptr;     size_t d_views_cap = 0;
-    void *d_stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // src, sdepth, rgba, depth, hit
-    size_t d_stage_cap[5] = {0, 0, 0, 0, 0};
+    void *d_stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // src, sdepth, rgba, depth, hit, steps
+    size_t d_stage_cap[6] = {0, 0, 0, 0, 0, 0};
 
-    // persistent-kernel queue state (see RmQueue)
-    uint32_t *d_queue = nullptr; size_t d_queue_cap = 0;   // counters | heavy_count | heavy_list | bitmaps
-    uint32_t q_bm_cap = 0;         // capacity of one heavy bitmap in words
-    uint32_t q_epoch = 0;
-    bool q_dirty = false;          // a queue launch failed: counters/lists are in an unknown rotation state
-    uint32_t q_last_tiles = 0, q_last_tx = 0, q_last_ty = 0; int q_last_mode = -1;
+    QueueState q;                  // persistent-kernel queue state in memory this context owns
     int n_cus = 0;
-    int occ[7][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};   // resident blocks per CU by kernel variant (6 = fractal)
-    int occ_stream[7][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    size_t lds_per_block = 0;
+    std::map<uint64_t, int> occ;   // resident blocks per CU, keyed by kernel family, variant and dynamic LDS bytes
 
     int inv_w_for = 0, inv_h_for = 0;       // frame sizes the reciprocals below were verified for
     float inv_w = 0.0f, inv_h = 0.0f;
 
-    hipStream_t last_stream = nullptr;
+    // the last launch: where its counters are and how to wait for it
+    uint32_t *last_partials = nullptr;
+    unsigned long long *last_stats = nullptr;
+    unsigned last_blocks = 0;
+    hipStream_t last_stream = nullptr;      // only used to wait for a launch that left no event (the entry point that allocates nothing)
+    bool last_has_event = false;
     uint64_t last_pixels = 0;
     bool have_last = false;
 };
@@ -298,15 +321,45 @@ void make_view(const mat4 &fc, const mat4 &c2w, const float cam_pos[3], RmView *
     corner_world(c2w, fc, 3, v->bl);
 }
 
-// first use of the device (the caller has made it current through a DeviceScope)
+// what every launch needs to know about the GPU; no memory is allocated here
+int ensure_props(rm_ctx *c) {
+    if (c->props_ready) return RM_OK;
+    int n = 0, lds = 0;
+    RM_HIP(c, hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->device));
+    RM_HIP(c, hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device));
+    c->n_cus = n > 0 ? n : 256;
+    c->lds_per_block = lds > 0 ? (size_t)lds : 65536;
+    c->props_ready = true;
+    return RM_OK;
+}
+
+// first use of the device by an entry point that may allocate (the caller has made it current through a DeviceScope)
 int ensure_device(rm_ctx *c) {
     if (c->dev_ready) return RM_OK;
-    RM_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    RM_HIP(c, hipMalloc((void **)&c->d_stats, 4 * sizeof(unsigned long long)));
-    hipDeviceProp_t prop;
-    RM_HIP(c, hipGetDeviceProperties(&prop, c->device));
-    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    int rc = ensure_props(c);
+    if (rc) return rc;
+    if (!c->stream) RM_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (!c->ev_last) RM_HIP(c, hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming));
+    if (!c->d_stats) RM_HIP(c, hipMalloc((void **)&c->d_stats, 4 * sizeof(unsigned long long)));
     c->dev_ready = true;
+    return RM_OK;
+}
+
+// Host-side wait for everything this context has launched.  Launches of the allocating entry points leave an
+// event; the entry point that allocates nothing leaves only the stream it was given, which must still exist.
+int wait_for_last(rm_ctx *c) {
+    if (!c->have_last) return RM_OK;
+    if (c->last_has_event) RM_HIP(c, hipEventSynchronize(c->ev_last));
+    else RM_HIP(c, hipStreamSynchronize(c->last_stream));
+    return RM_OK;
+}
+
+// Orders `stream` behind the context's previous launch, whatever stream that ran on: the queue counters,
+// counter slots, primitive table and view array are shared by consecutive launches.
+int order_after_last(rm_ctx *c, hipStream_t stream) {
+    if (!c->have_last) return RM_OK;
+    if (c->last_has_event) RM_HIP(c, hipStreamWaitEvent(stream, c->ev_last, 0));
+    else if (c->last_stream != stream) RM_HIP(c, hipStreamSynchronize(c->last_stream));
     return RM_OK;
 }
 
@@ -394,8 +447,9 @@ int build_params(rm_ctx *c, RmParams *U, hipStream_t stream) {
             int rc = ensure_cap(c, &c->d_prims, &c->d_prims_cap, n * sizeof(RmPrimDev));
             if (rc) return rc;
             // the table must be in place before any later launch reads it, and the
-            // host vector dies at return: a blocking copy, done only when the scene changed
-            RM_HIP(c, hipStreamSynchronize(stream));
+            // host vector dies at return: a blocking copy, done only when the scene changed,
+            // after every earlier launch (on whatever stream) has finished with the old table
+            if ((rc = wait_for_last(c))) return rc;
             RM_HIP(c, hipMemcpy(c->d_prims, t.data(), n * sizeof(RmPrimDev), hipMemcpyHostToDevice));
             c->prims_dirty = false;
         }
@@ -475,59 +529,78 @@ constexpr uint32_t RM_STATIC_TILES_MAX = 6;      // static tiles per wave at mos
 constexpr uint32_t RM_HEAVY_CAP = 8192;          // heavy-tile list entries kept per frame
 constexpr uint32_t RM_QUEUE_MAX_TILES = 160u * 1024u;   // 20 KB of LDS bitmap per block at most (4K frame = 129600 tiles)
 
-int ensure_partials(rm_ctx *c, unsigned slots, hipStream_t stream) {
+int ensure_partials(rm_ctx *c, WorkMem &M, unsigned slots) {
     size_t bytes = (size_t)slots * 4 * rm_slot_words();
-    if (bytes <= c->d_partials_cap) return RM_OK;
+    if (bytes <= *M.partials_cap) return RM_OK;
+    if (M.fixed) return fail(c, RM_E_RANGE, "frame needs more counter slots than the static scratch holds");
     // growing the slot buffer frees the old one: earlier launches must have finished with it
-    RM_HIP(c, hipStreamSynchronize(stream));
-    if (c->have_last) RM_HIP(c, hipStreamSynchronize(c->last_stream));
-    return ensure_cap(c, &c->d_partials, &c->d_partials_cap, bytes);
+    int rc = wait_for_last(c);
+    if (rc) return rc;
+    return ensure_cap(c, M.partials, M.partials_cap, bytes);
 }
 
-int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, bool streamk) {
+size_t queue_words(uint32_t bm_cap) { return RM_Q_HDR + 3 * (size_t)RM_HEAVY_CAP + 3 * (size_t)bm_cap; }
+
+// RM_OK, an error, or RM_FALLBACK_TILE when the persistent kernel cannot run this launch (its dynamic LDS does
+// not fit a workgroup) and the caller did not insist on it
+constexpr int RM_FALLBACK_TILE = 1;
+
+int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, bool streamk, WorkMem &M, bool forced) {
+    QueueState &S = *M.q;
     const uint32_t tx = (uint32_t)(P.w + RM_TW - 1) / RM_TW, ty = (uint32_t)(P.rows + RM_TH - 1) / RM_TH;
     const uint64_t n_tiles64 = (uint64_t)tx * ty * (uint64_t)P.n_poses;
     if (n_tiles64 > 0x7fffffffull) return fail(c, RM_E_RANGE, "more than 2^31 tiles in one launch: split the pose batch");
     const uint32_t n_tiles = (uint32_t)n_tiles64;
+    // the heavy bitmap lives in LDS: keep history only while it fits comfortably beside 4+ blocks per CU
+    bool keep_history = !streamk && n_tiles <= RM_QUEUE_MAX_TILES;
+    uint32_t bm_words = keep_history ? (n_tiles + 31) / 32 : 0;
+    if (M.fixed && bm_words > S.bm_cap) { keep_history = false; bm_words = 0; }
+    RmQueue &Q = P.queue;
+    Q.bitmap_words = bm_words;
+
+    // dynamic LDS of this launch: bitmap (+ staged primitive table), known before anything is asked of the runtime
+    const size_t table_bytes = (size_t)P.lds_prims * sizeof(RmPrimDev);
+    const size_t lds_bytes = streamk ? table_bytes : (size_t)((bm_words + 3u) & ~3u) * 4 + (P.n_prims > 0 ? table_bytes : 0);
+    if (lds_bytes + 256 > c->lds_per_block) {
+        if (!forced) return RM_FALLBACK_TILE;
+        return fail(c, RM_E_RANGE, "the persistent kernel's tile bitmap and primitive table do not fit one workgroup's LDS for this frame");
+    }
     const int vi = rm_variant_index(P), tab = P.n_prims > 0 ? 1 : 0;
-    int (*occ)[2] = streamk ? c->occ_stream : c->occ;
-    if (occ[vi][tab] == 0) {
+    const uint64_t occ_key = ((uint64_t)(streamk ? 1 : 0) << 60) | ((uint64_t)vi << 52) | ((uint64_t)tab << 48) | (uint64_t)lds_bytes;
+    auto occ_it = c->occ.find(occ_key);
+    if (occ_it == c->occ.end()) {
         int o[2] = {0, 0};
         RM_HIP(c, streamk ? rm_launch_stream(P, 0, stream, o) : rm_launch_queue(P, 0, stream, o));
-        occ[vi][0] = o[0] > 0 ? o[0] : 1;
-        occ[vi][1] = o[1] > 0 ? o[1] : 1;
+        occ_it = c->occ.emplace(occ_key, o[tab] > 0 ? o[tab] : 1).first;
     }
-    // the heavy bitmap lives in LDS: keep history only while it fits comfortably beside 4+ blocks per CU
-    const bool keep_history = !streamk && n_tiles <= RM_QUEUE_MAX_TILES;
-    const uint32_t bm_words = keep_history ? (n_tiles + 31) / 32 : 0;
-    if (!c->d_queue || bm_words > c->q_bm_cap) {
-        RM_HIP(c, hipStreamSynchronize(stream));
-        if (c->have_last) RM_HIP(c, hipStreamSynchronize(c->last_stream));
-        uint32_t cap = bm_words > c->q_bm_cap ? bm_words : c->q_bm_cap;
-        if (cap < 64) cap = 64;
-        size_t words = RM_Q_HDR + 3 * (size_t)RM_HEAVY_CAP + 3 * (size_t)cap;
-        int rc = ensure_cap(c, &c->d_queue, &c->d_queue_cap, words * 4);
+
+    if (!S.buf || bm_words > S.bm_cap) {
+        // (never reached with static scratch: its buffer exists and bm_words was capped above)
+        int rc = wait_for_last(c);
         if (rc) return rc;
-        RM_HIP(c, hipMemset(c->d_queue, 0, words * 4));
-        c->q_bm_cap = cap;
-        c->q_last_mode = -1;                         // history gone
+        uint32_t cap = bm_words > S.bm_cap ? bm_words : S.bm_cap;
+        if (cap < 64) cap = 64;
+        rc = ensure_cap(c, &S.buf, &S.cap_bytes, queue_words(cap) * 4);
+        if (rc) return rc;
+        S.bm_cap = cap;
+        S.zeroed = false; S.dirty = true;            // fresh memory: cleared below, in stream order
+        S.history = false;
     }
-    RmQueue &Q = P.queue;
-    Q.counters = c->d_queue;
-    Q.heavy_count = c->d_queue + 2 * RM_Q_SHARDS * RM_Q_STRIDE;
-    Q.heavy_list = c->d_queue + RM_Q_HDR;
+    Q.counters = S.buf;
+    Q.heavy_count = S.buf + 2 * RM_Q_SHARDS * RM_Q_STRIDE;
+    Q.heavy_list = S.buf + RM_Q_HDR;
     Q.bitmaps = Q.heavy_list + 3 * (size_t)RM_HEAVY_CAP;
     Q.n_tiles = n_tiles; Q.tiles_x = tx; Q.tiles_y = ty;
     Q.tx_magic = ((1ull << 37) + tx - 1) / tx;            // tiles per pose < 2^24, tx <= 4096: (t * magic) >> 37 == t / tx
-    const bool same_shape = c->q_last_mode == P.mode && c->q_last_tiles == n_tiles && c->q_last_tx == tx && c->q_last_ty == ty;
-    if (c->q_dirty || (keep_history && !same_shape && c->q_last_mode != -1)) {
-        // the three bitmap sets were laid out for another tile count: start clean
-        RM_HIP(c, hipStreamSynchronize(stream));
-        if (c->have_last) RM_HIP(c, hipStreamSynchronize(c->last_stream));
-        RM_HIP(c, hipMemset(c->d_queue, 0, c->d_queue_cap));
-        c->q_dirty = false;
+    const bool same_shape = S.history && S.last_mode == P.mode && S.last_tiles == n_tiles && S.last_tx == tx && S.last_ty == ty;
+    if (S.dirty || (keep_history && !same_shape && !S.zeroed)) {
+        // The three bitmap sets were laid out for another tile count, or a launch that kept no history has
+        // rotated past them without clearing: start clean.  The stream is already ordered behind the
+        // context's previous launch, so the clear needs no host-side wait.
+        RM_HIP(c, hipMemsetAsync(S.buf, 0, queue_words(S.bm_cap) * 4, stream));
+        S.dirty = false;
+        S.history = false;
     }
-    Q.bitmap_words = bm_words;
     {
         static const uint32_t primes[] = {7919u, 7907u, 7901u, 7883u, 7879u, 7877u, 7873u, 7867u};
         Q.scatter_mul = 1;
@@ -537,14 +610,15 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, bool streamk) {
     Q.heavy_cap = RM_HEAVY_CAP;
     float thr = getf(c, "_RmHeavyTileThreshold", 24.0f);
     Q.heavy_threshold = keep_history && thr > 0.0f ? (uint32_t)thr : 0xffffffffu;
-    const uint32_t e = ++c->q_epoch;
+    const uint32_t e = ++S.epoch;
     Q.use_history = (keep_history && getf(c, "_RmTileFeedback", 1.0f) != 0.0f && same_shape) ? 1u : 0u;
     Q.cnt_cur = e & 1u; Q.cnt_clr = (e + 1u) & 1u;
     Q.hv_cur = e % 3u; Q.hv_nxt = (e + 1u) % 3u; Q.hv_clr = (e + 2u) % 3u;
-    c->q_last_mode = keep_history ? P.mode : -1;
-    c->q_last_tiles = n_tiles; c->q_last_tx = tx; c->q_last_ty = ty;
+    S.zeroed = false;
+    S.history = keep_history;
+    S.last_mode = P.mode; S.last_tiles = n_tiles; S.last_tx = tx; S.last_ty = ty;
 
-    unsigned per_cu = (unsigned)occ[vi][tab];
+    unsigned per_cu = (unsigned)occ_it->second;
     const float cap_per_cu = getf(c, "_RmBlocksPerCU", 0.0f);      // 0: as many as fit
     if (cap_per_cu >= 1.0f && (unsigned)cap_per_cu < per_cu) per_cu = (unsigned)cap_per_cu;
     unsigned resident = (unsigned)c->n_cus * per_cu;
@@ -565,16 +639,16 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, bool streamk) {
         frac = frac > 1.0f ? 1.0f : frac;
         Q.static_per_wave = (uint32_t)(frac * per_wave);
     }
-    int rc = ensure_partials(c, blocks * 4, stream);
-    if (rc) return rc;
-    P.partials = c->d_partials;
+    int rc = ensure_partials(c, M, blocks * 4);
+    if (rc) { S.dirty = true; return rc; }
+    P.partials = *M.partials;
     {
         // every frame clears the counter set and lists of a later frame: if this launch does not happen,
         // that rotation is broken and the next launch has to start from a zeroed state
         hipError_t le = streamk ? rm_launch_stream(P, blocks, stream, nullptr) : rm_launch_queue(P, blocks, stream, nullptr);
         if (le != hipSuccess) {
-            c->q_dirty = true;
-            c->q_last_mode = -1;
+            S.dirty = true;
+            S.history = false;
             return fail(c, RM_E_DEVICE, std::string("queue kernel launch: ") + hipGetErrorString(le));
         }
     }
@@ -582,7 +656,14 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, bool streamk) {
     return RM_OK;
 }
 
-int launch(rm_ctx *c, const RmParams &U, hipStream_t stream) {
+WorkMem own_mem(rm_ctx *c) {
+    WorkMem M;
+    M.q = &c->q; M.partials = &c->d_partials; M.partials_cap = &c->d_partials_cap; M.stats = c->d_stats; M.fixed = false;
+    return M;
+}
+
+// `record`: leave an event behind the launch (every entry point but the one that allocates nothing)
+int launch(rm_ctx *c, const RmParams &U, hipStream_t stream, WorkMem M, bool record) {
     RmParams P = U;
     frame_reciprocals(c, U.w, U.h, &P);
     // auto: the persistent queue kernel pays on the 4-slot scene, whose frames are a mass of cheap
@@ -591,25 +672,38 @@ int launch(rm_ctx *c, const RmParams &U, hipStream_t stream) {
     // (the fractal bodies are uniformly expensive too: measured 1.18 ms tile vs 1.57 ms queue at 1080p)
     // (the depth passes have no shadow march and hence no long tiles either: 4K directional pass 276 us tile vs
     // 311 us queue; keeping them off the persistent kernel also keeps their tile costs out of the frag pass's history)
-    int kernel = c->kernel != RM_KERNEL_AUTO ? c->kernel
+    const bool forced = c->kernel != RM_KERNEL_AUTO;
+    int kernel = forced ? c->kernel
                : ((U.n_prims > 0 || U.body != RM_BODY_PRIMS || U.mode != RM_MODE_FRAG) ? RM_KERNEL_TILE : RM_KERNEL_QUEUE);
     if (U.body != RM_BODY_PRIMS && kernel == RM_KERNEL_STREAM) kernel = RM_KERNEL_QUEUE;      // no stream kernel for the fractal bodies
     if (U.mode == RM_MODE_FRAG && (U.fx_flags != 0 || U.fx_view != 0)) kernel = RM_KERNEL_TILE;   // the optional frag lines exist in the tile kernels only
     if (U.dom_op != RM_DOM_NONE) kernel = RM_KERNEL_TILE;                                          // and so do the domain operators
+    if (U.dst_steps) kernel = RM_KERNEL_TILE;                                                      // and the per-pixel step-count plane
+    int rc = order_after_last(c, stream);
+    if (rc) return rc;
+    if (kernel != RM_KERNEL_TILE) {
+        rc = launch_queue(c, P, stream, kernel == RM_KERNEL_STREAM, M, forced);
+        if (rc == RM_FALLBACK_TILE) kernel = RM_KERNEL_TILE;
+        else if (rc) return rc;
+    }
     if (kernel == RM_KERNEL_TILE) {
         unsigned n_blocks = rm_tile_blocks(U.w, U.rows, U.n_poses);
-        int rc = ensure_partials(c, n_blocks, stream);
+        rc = ensure_partials(c, M, n_blocks);
         if (rc) return rc;
-        P.partials = c->d_partials;
+        P.partials = *M.partials;
         RM_HIP(c, rm_launch_tiles(P, stream));
         c->last_blocks = n_blocks;
-    } else {
-        int rc = launch_queue(c, P, stream, kernel == RM_KERNEL_STREAM);
-        if (rc) return rc;
     }
+    c->last_partials = *M.partials;
+    c->last_stats = M.stats;
     c->last_stream = stream;
+    c->last_has_event = false;
     c->last_pixels = (uint64_t)U.w * (uint64_t)U.rows * (uint64_t)U.n_poses;
     c->have_last = true;
+    if (record) {
+        RM_HIP(c, hipEventRecord(c->ev_last, stream));
+        c->last_has_event = true;
+    }
     return RM_OK;
 }
 
@@ -646,13 +740,14 @@ void rm_destroy(rm_ctx *c) {
         DeviceScope ds;
         (void)ds.enter(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
-        if (c->last_stream) (void)hipStreamSynchronize(c->last_stream);
-        for (int i = 0; i < 5; i++) if (c->d_stage[i]) (void)hipFree(c->d_stage[i]);
+        (void)wait_for_last(c);
+        for (int i = 0; i < 6; i++) if (c->d_stage[i]) (void)hipFree(c->d_stage[i]);
         if (c->d_prims) (void)hipFree(c->d_prims);
         if (c->d_views) (void)hipFree(c->d_views);
         if (c->d_stats) (void)hipFree(c->d_stats);
         if (c->d_partials) (void)hipFree(c->d_partials);
-        if (c->d_queue) (void)hipFree(c->d_queue);
+        if (c->q.buf) (void)hipFree(c->q.buf);
+        if (c->ev_last) (void)hipEventDestroy(c->ev_last);
         if (c->stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
@@ -769,15 +864,14 @@ int rm_band_rows(int h, int band_rows, int part, int n_parts) {
     return rows;
 }
 
-int rm_blit_bands_device(rm_ctx *c, const void *d_src, const void *d_sdepth, void *d_rgba, void *d_depth, void *d_hit,
-                         int w, int h, int band_rows, int part, int n_parts, void *hip_stream) {
-    RM_TRY
-    if (!c) return RM_E_ARG;
+static int blit_device_common(rm_ctx *c, const void *d_src, const void *d_sdepth, void *d_rgba, void *d_depth, void *d_hit,
+                              void *d_steps, int w, int h, int band_rows, int part, int n_parts, void *hip_stream) {
     int rc = check_size(c, w, h);
     if (rc) return rc;
     int rows = rm_band_rows(h, band_rows, part, n_parts);
     if (rows < 0) return fail(c, RM_E_ARG, "rm_blit_bands_device: bad band arguments");
     if (rows == 0) return RM_OK;
+    if (d_steps && ((uintptr_t)d_steps & 3u)) return fail(c, RM_E_ARG, "step-count plane must be 4-byte aligned");
     DeviceScope ds;
     RM_HIP(c, ds.enter(c->device));
     if ((rc = ensure_device(c))) return rc;
@@ -789,7 +883,15 @@ int rm_blit_bands_device(rm_ctx *c, const void *d_src, const void *d_sdepth, voi
     U.mode = RM_MODE_FRAG;
     U.src = (const uint8_t *)d_src; U.sdepth = (const float *)d_sdepth;
     U.dst_rgba = (uint8_t *)d_rgba; U.dst_depth = (float *)d_depth; U.dst_hit = (uint8_t *)d_hit;
-    return launch(c, U, stream);
+    U.dst_steps = (uint32_t *)d_steps;
+    return launch(c, U, stream, own_mem(c), true);
+}
+
+int rm_blit_bands_device(rm_ctx *c, const void *d_src, const void *d_sdepth, void *d_rgba, void *d_depth, void *d_hit,
+                         int w, int h, int band_rows, int part, int n_parts, void *hip_stream) {
+    RM_TRY
+    if (!c) return RM_E_ARG;
+    return blit_device_common(c, d_src, d_sdepth, d_rgba, d_depth, d_hit, nullptr, w, h, band_rows, part, n_parts, hip_stream);
     RM_CATCH(c)
 }
 
@@ -797,7 +899,15 @@ int rm_blit_device(rm_ctx *c, const void *d_src, const void *d_sdepth, void *d_r
                    int w, int h, void *hip_stream) {
     RM_TRY
     if (!c) return RM_E_ARG;
-    return rm_blit_bands_device(c, d_src, d_sdepth, d_rgba, d_depth, d_hit, w, h, h > 0 ? h : 1, 0, 1, hip_stream);
+    return blit_device_common(c, d_src, d_sdepth, d_rgba, d_depth, d_hit, nullptr, w, h, h > 0 ? h : 1, 0, 1, hip_stream);
+    RM_CATCH(c)
+}
+
+int rm_blit_steps_device(rm_ctx *c, const void *d_src, const void *d_sdepth, void *d_rgba, void *d_depth, void *d_hit,
+                         void *d_steps, int w, int h, void *hip_stream) {
+    RM_TRY
+    if (!c) return RM_E_ARG;
+    return blit_device_common(c, d_src, d_sdepth, d_rgba, d_depth, d_hit, d_steps, w, h, h > 0 ? h : 1, 0, 1, hip_stream);
     RM_CATCH(c)
 }
 
@@ -822,42 +932,59 @@ int rm_blit_poses_device(rm_ctx *c, int n_poses, const float *fcs, const float *
         std::memcpy(c2w.data(), c2ws + (size_t)i * 16, 64);
         make_view(fc, c2w, cam_pos + (size_t)i * 3, &views[(size_t)i]);
     }
+    // earlier launches (on whatever stream) may still read the previous views
+    if ((rc = wait_for_last(c))) return rc;
     if ((rc = ensure_cap(c, &c->d_views, &c->d_views_cap, views.size() * sizeof(RmView)))) return rc;
-    // earlier launches on this stream may still read the previous views
-    RM_HIP(c, hipStreamSynchronize(stream));
     RM_HIP(c, hipMemcpy(c->d_views, views.data(), views.size() * sizeof(RmView), hipMemcpyHostToDevice));
     U.views = c->d_views;
     U.n_poses = n_poses;
     U.w = w; U.h = h; U.rows = h; U.band_rows = h;
     U.mode = RM_MODE_FRAG;
     U.dst_rgba = (uint8_t *)d_rgba; U.dst_depth = (float *)d_depth; U.dst_hit = (uint8_t *)d_hit;
-    return launch(c, U, stream);
+    return launch(c, U, stream, own_mem(c), true);
     RM_CATCH(c)
 }
 
-int rm_blit(rm_ctx *c, const uint8_t *src, const float *sdepth, uint8_t *rgba, float *depth, uint8_t *hit, int w, int h) {
-    RM_TRY
-    if (!c) return RM_E_ARG;
+static int blit_host_common(rm_ctx *c, const uint8_t *src, const float *sdepth, uint8_t *rgba, float *depth, uint8_t *hit,
+                            uint16_t *steps, int w, int h) {
     int rc = check_size(c, w, h);
     if (rc) return rc;
     DeviceScope ds;
     RM_HIP(c, ds.enter(c->device));
     if ((rc = ensure_device(c))) return rc;
     size_t n = (size_t)w * (size_t)h;
+    // the staging buffers may still be read or written by this context's previous launch on another stream
+    if ((rc = order_after_last(c, c->stream))) return rc;
     if (src)    { if ((rc = stage(c, 0, n * 4))) return rc; RM_HIP(c, hipMemcpyAsync(c->d_stage[0], src, n * 4, hipMemcpyHostToDevice, c->stream)); }
     if (sdepth) { if ((rc = stage(c, 1, n * 4))) return rc; RM_HIP(c, hipMemcpyAsync(c->d_stage[1], sdepth, n * 4, hipMemcpyHostToDevice, c->stream)); }
     if (rgba)  if ((rc = stage(c, 2, n * 4))) return rc;
     if (depth) if ((rc = stage(c, 3, n * 4))) return rc;
     if (hit)   if ((rc = stage(c, 4, n))) return rc;
-    rc = rm_blit_device(c, src ? c->d_stage[0] : nullptr, sdepth ? c->d_stage[1] : nullptr,
-                        rgba ? c->d_stage[2] : nullptr, depth ? c->d_stage[3] : nullptr, hit ? c->d_stage[4] : nullptr,
-                        w, h, c->stream);
+    if (steps) if ((rc = stage(c, 5, n * 4))) return rc;
+    rc = blit_device_common(c, src ? c->d_stage[0] : nullptr, sdepth ? c->d_stage[1] : nullptr,
+                            rgba ? c->d_stage[2] : nullptr, depth ? c->d_stage[3] : nullptr, hit ? c->d_stage[4] : nullptr,
+                            steps ? c->d_stage[5] : nullptr, w, h, h, 0, 1, c->stream);
     if (rc) return rc;
     if (rgba)  RM_HIP(c, hipMemcpyAsync(rgba, c->d_stage[2], n * 4, hipMemcpyDeviceToHost, c->stream));
     if (depth) RM_HIP(c, hipMemcpyAsync(depth, c->d_stage[3], n * 4, hipMemcpyDeviceToHost, c->stream));
     if (hit)   RM_HIP(c, hipMemcpyAsync(hit, c->d_stage[4], n, hipMemcpyDeviceToHost, c->stream));
+    if (steps) RM_HIP(c, hipMemcpyAsync(steps, c->d_stage[5], n * 4, hipMemcpyDeviceToHost, c->stream));
     RM_HIP(c, hipStreamSynchronize(c->stream));
     return RM_OK;
+}
+
+int rm_blit(rm_ctx *c, const uint8_t *src, const float *sdepth, uint8_t *rgba, float *depth, uint8_t *hit, int w, int h) {
+    RM_TRY
+    if (!c) return RM_E_ARG;
+    return blit_host_common(c, src, sdepth, rgba, depth, hit, nullptr, w, h);
+    RM_CATCH(c)
+}
+
+int rm_blit_steps(rm_ctx *c, const uint8_t *src, const float *sdepth, uint8_t *rgba, float *depth, uint8_t *hit,
+                  uint16_t *steps, int w, int h) {
+    RM_TRY
+    if (!c) return RM_E_ARG;
+    return blit_host_common(c, src, sdepth, rgba, depth, hit, steps, w, h);
     RM_CATCH(c)
 }
 
@@ -879,7 +1006,7 @@ static int depth_pass_device(rm_ctx *c, int mode, const float corners[12], const
         std::memcpy(U.ortho_fwd, forward, sizeof(float) * 3);
     }
     U.dst_depth = (float *)d_depth; U.dst_hit = (uint8_t *)d_hit;
-    return launch(c, U, stream);
+    return launch(c, U, stream, own_mem(c), true);
     RM_CATCH(c)
 }
 
@@ -958,13 +1085,14 @@ int rm_debug_counter_slots(rm_ctx *c, uint32_t *out, int max_words, int *words_p
     if (!c || !c->have_last) return fail(c, RM_E_ARG, "rm_debug_counter_slots: no blit has run");
     DeviceScope ds;
     RM_HIP(c, ds.enter(c->device));
-    RM_HIP(c, hipStreamSynchronize(c->last_stream));
+    int rc = wait_for_last(c);
+    if (rc) return rc;
     size_t words = (size_t)c->last_blocks * rm_slot_words();
     if (words_per_slot) *words_per_slot = (int)rm_slot_words();
     if (n_slots) *n_slots = (int)c->last_blocks;
     if (out && max_words > 0) {
         if (words > (size_t)max_words) words = (size_t)max_words;
-        RM_HIP(c, hipMemcpy(out, c->d_partials, words * 4, hipMemcpyDeviceToHost));
+        RM_HIP(c, hipMemcpy(out, c->last_partials, words * 4, hipMemcpyDeviceToHost));
     }
     return RM_OK;
     RM_CATCH(c)
@@ -976,10 +1104,18 @@ int rm_get_stats(rm_ctx *c, rm_stats *out) {
     if (!c->have_last) return fail(c, RM_E_ARG, "rm_get_stats: no blit has run");
     DeviceScope ds;
     RM_HIP(c, ds.enter(c->device));
-    RM_HIP(c, rm_reduce_stats(c->d_partials, c->last_blocks, c->d_stats, c->last_stream));
-    RM_HIP(c, hipStreamSynchronize(c->last_stream));
+    // The reduction runs on the context's own stream, ordered behind the last launch by its event: the stream
+    // that launch was given is the caller's and may be gone by now.  A launch of the entry point that
+    // allocates nothing leaves no event; its stream is used, and must still exist.
+    hipStream_t s = c->last_stream;
+    if (c->last_has_event) {
+        s = c->stream;
+        RM_HIP(c, hipStreamWaitEvent(s, c->ev_last, 0));
+    }
+    RM_HIP(c, rm_reduce_stats(c->last_partials, c->last_blocks, c->last_stats, s));
+    RM_HIP(c, hipStreamSynchronize(s));
     unsigned long long v[4];
-    RM_HIP(c, hipMemcpy(v, c->d_stats, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    RM_HIP(c, hipMemcpy(v, c->last_stats, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     out->n_pixels = c->last_pixels;
     out->n_hit = v[0];
     out->sum_steps_p = v[1];

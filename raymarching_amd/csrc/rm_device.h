@@ -125,6 +125,8 @@ struct RmParams {
     uint8_t  *dst_rgba;
     float    *dst_depth;
     uint8_t  *dst_hit;
+    uint32_t *dst_steps;       // optional, tile kernels only: per pixel, scene() evaluations of the primary march (low 16 bits,
+                               // ray.steps of cginc:37,387 counted in evaluations) and of the shadow march (high 16 bits)
     uint32_t *partials;        // counter slots (per block or per wave): n_hit, primary evals, shadow evals
     RmQueue   queue;           // persistent kernel only
     RmPrimDev prims4[4];

@@ -89,7 +89,7 @@ RM_DI float rm_getshadow(const S &sc, V3 p, V3 n, V3 L, float contact, float dep
 #define RM_LDS __attribute__((address_space(3)))
 typedef const volatile RM_LDS float *rm_lds_cfloat;
 
-struct PixelOut { uint32_t rgba; float depth; uint32_t hit; size_t oidx; };
+struct PixelOut { uint32_t rgba; float depth; uint32_t hit; size_t oidx; uint32_t steps; };
 
 // Ray of pixel (x, local row yl, pose): origin, un-normalised direction, march depth limit,
 // and the pixel's index in the full frame (inputs) and in the compact output.
@@ -169,6 +169,7 @@ RM_DI PixelOut rm_compute_pixel(const RmParams &U, const S &sc, int x, int yl, i
     out.depth = r.length;
     out.hit = r.hit ? 1u : 0u;
     out.rgba = 0;
+    out.steps = 0;
 
     if (U.mode == RM_MODE_FRAG) {
         if (r.hit) {
@@ -246,6 +247,7 @@ RM_DI PixelOut rm_compute_pixel_fx(const RmParams &U, const S &sc, int x, int yl
     out.depth = r.length;
     out.hit = r.hit ? 1u : 0u;
     out.rgba = 0;
+    out.steps = 0;
     if (U.mode != RM_MODE_FRAG) return out;
 
     V3 col;
@@ -308,6 +310,10 @@ RM_DI void rm_store_pixel(const RmParams &U, const PixelOut &o) {
     if (U.dst_depth) U.dst_depth[o.oidx] = o.depth;
     if (U.dst_hit) U.dst_hit[o.oidx] = (uint8_t)o.hit;
 }
+// the optional per-pixel step-count plane (the reference's nearest thing is the commented-out heat map, shader:203)
+RM_DI void rm_store_steps(const RmParams &U, const PixelOut &o) {
+    if (U.dst_steps) U.dst_steps[o.oidx] = o.steps;
+}
 
 // wave-wide maximum, returned as a uniform value: a butterfly inside each 16-lane row with DPP
 // modifiers (no LDS crossbar, no waitcnt), then one lane per row read back and combined on the
@@ -346,9 +352,13 @@ RM_DI void rm_pixel(const RmParams &U, const S &sc) {
     const int lane = tid & 63, wv = tid >> 6;
     const int x  = blockIdx.x * (8 * RM_BWX) + (wv % RM_BWX) * 8 + (lane & 7);
     const int yl = blockIdx.y * (8 * RM_BWY) + (wv / RM_BWX) * 8 + (lane >> 3);
-    if (x < U.w && yl < U.rows)
-        rm_store_pixel(U, FX ? rm_compute_pixel_fx(U, sc, x, yl, (int)blockIdx.z, c_hit, c_p, c_s)
-                             : rm_compute_pixel(U, sc, x, yl, (int)blockIdx.z, c_hit, c_p, c_s));
+    if (x < U.w && yl < U.rows) {
+        PixelOut po = FX ? rm_compute_pixel_fx(U, sc, x, yl, (int)blockIdx.z, c_hit, c_p, c_s)
+                         : rm_compute_pixel(U, sc, x, yl, (int)blockIdx.z, c_hit, c_p, c_s);
+        po.steps = c_p | (c_s << 16);          // this thread's only pixel: the counters are the pixel's own (<= 2000 each)
+        rm_store_pixel(U, po);
+        rm_store_steps(U, po);
+    }
 
     // Counters: per-wave sums by cross-lane shuffles, per-block sums in LDS, then ONE plain
     // store per counter into this block's own slot.  No global atomics: same-address atomics

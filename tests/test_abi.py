@@ -149,4 +149,5 @@ def test_kernels_do_not_spill():
         if name in ("rm_queue_kernel4<rot=0, scl=0>", "rm_tile_kernel4<rot=0, scl=0>", "rm_tile_kernelF"):
             assert scratch == 0, f"{name} spills {scratch} B"           # the reference scene's kernels and the fractal kernel
         if name.startswith(("rm_queue_kernel4", "rm_tile_kernel")):
-            assert scratch <= 96, f"{name} spills {scratch} B"           # every kernel the automatic choice can pick
+            # every kernel the automatic choice can pick; the kernels with frag's optional lines carry more state
+            assert scratch <= (128 if "_fx" in name else 96), f"{name} spills {scratch} B"

@@ -335,3 +335,130 @@ def test_rgb_pack_round_trip(torch_cuda):
             assert torch.equal(back[:, :3], rgba[:, :3]) and bool((back[:, 3] == 255).all())
             with pytest.raises(RuntimeError):
                 mat.pack_rgb(rgba[:3], rgb[:3])            # not a multiple of 4 pixels
+
+
+def _frames_of(case_names, oracle):
+    return {n: cases.oracle_run(cases.BY_NAME[n], oracle) for n in case_names}
+
+
+def test_one_context_across_sizes_kernels_and_pose_batches(oracle, torch_cuda):
+    """One context reused the way a player does: frames at one size, a launch that keeps no tile history (the
+    lane-compaction kernel, a pose batch with more tiles than the history bitmap holds), then frames at another size
+    and another camera.  The persistent kernel's frame-to-frame state (claim counters, heavy-tile lists and bitmaps)
+    must never leak from one shape into the next: every frame equals the oracle's bit for bit."""
+    torch = torch_cuda
+    from raymarching_amd import Material, Raymarching, RenderTexture, scenes
+    from raymarching_amd.material import _fp, _ptr, current_stream_handle
+    dev = "cuda:0"
+    ref = _frames_of(["default_640x360", "orbit_k5_480x270", "orbit_k23_480x270", "orbit_k40_480x270"], oracle)
+
+    def frame(mat, w, h, cam):
+        rm = Raymarching(cam, mat, scenes.default_transforms())
+        rt = RenderTexture(w, h, device=dev)
+        rm.OnRenderImage(None, rt)
+        st = mat.stats()
+        torch.cuda.synchronize()
+        return {"rgba": rt.color.cpu().numpy(), "depth": rt.depth.cpu().numpy(), "hit": rt.hit.cpu().numpy(), "stats": st}
+
+    def big_pose_batch(mat):
+        # 12 poses of 1920x1080 = 388 800 tiles: beyond the history bitmap, so this launch keeps no history
+        w, h, n = 1920, 1080, 12
+        cams = [Raymarching(scenes.orbit_camera(5 * k, 64, w, h), mat, scenes.default_transforms()) for k in range(n)]
+        fcs = np.ascontiguousarray(np.stack([r.GetFrustumCorners().m for r in cams]), dtype=np.float32)
+        c2ws = np.ascontiguousarray(np.stack([r.cam.cameraToWorldMatrix.m for r in cams]), dtype=np.float32)
+        pos = np.ascontiguousarray(np.stack([r.cam.transform.position for r in cams]), dtype=np.float32)
+        c = torch.zeros((n, h, w, 4), dtype=torch.uint8, device=dev)
+        d = torch.zeros((n, h, w), dtype=torch.float32, device=dev)
+        m = torch.zeros((n, h, w), dtype=torch.uint8, device=dev)
+        mat._ck(mat._lib.rm_blit_poses_device(mat.handle, n, _fp(fcs), _fp(c2ws), _fp(pos), _ptr(c), _ptr(d), _ptr(m), w, h,
+                                              current_stream_handle(dev)))
+        torch.cuda.synchronize()
+
+    for breaker in ("stream", "poses"):
+        with Material() as mat:
+            mat.SetVector("_WorldSpaceLightPos0", scenes.WORLD_SPACE_LIGHT_POS0)
+            mat.SetFloat("_RmHeavyTileThreshold", 6.0)          # many heavy tiles: stale bits would hide many tiles
+            mat.set_kernel(KERNELS["queue"])
+            for i in range(3):
+                assert_frame_equal(frame(mat, 640, 360, scenes.default_camera(640, 360)), ref["default_640x360"], f"{breaker} A{i}")
+            if breaker == "stream":
+                mat.set_kernel(KERNELS["stream"])
+                assert_frame_equal(frame(mat, 640, 360, scenes.default_camera(640, 360)), ref["default_640x360"], "stream frame")
+                mat.set_kernel(KERNELS["queue"])
+            else:
+                big_pose_batch(mat)
+            # another size, moving camera: every frame has the previous pose's heavy tiles as its history
+            for i, k in enumerate((5, 23, 40, 23, 5)):
+                got = frame(mat, 480, 270, scenes.orbit_camera(k, 64, 480, 270))
+                assert_frame_equal(got, ref[f"orbit_k{k}_480x270"], f"{breaker} B{i} pose {k}")
+                assert got["stats"]["sum_steps_p"] == ref[f"orbit_k{k}_480x270"]["stats"]["sum_steps_p"]
+            # and back to the first size
+            for i in range(2):
+                assert_frame_equal(frame(mat, 640, 360, scenes.default_camera(640, 360)), ref["default_640x360"], f"{breaker} C{i}")
+
+
+def test_consecutive_launches_on_different_streams(oracle, torch_cuda):
+    """a context driven from two caller streams in turn: the library orders each launch behind the previous one
+    (shared claim counters and counter slots), so every frame and every rm_get_stats is right"""
+    torch = torch_cuda
+    from raymarching_amd import Material, Raymarching, RenderTexture, scenes
+    from raymarching_amd.material import _ptr
+    dev = "cuda:0"
+    case = cases.BY_NAME["default_640x360"]
+    ref = cases.oracle_run(case, oracle)
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    with Material() as mat:
+        case.bind(mat)
+        mat.set_kernel(KERNELS["queue"])
+        rts = [RenderTexture(case.w, case.h, device=dev) for _ in range(6)]
+        torch.cuda.synchronize()
+        for i, rt in enumerate(rts):
+            s = streams[i & 1]
+            mat._ck(mat._lib.rm_blit_device(mat.handle, None, None, _ptr(rt.color), _ptr(rt.depth), _ptr(rt.hit), case.w, case.h,
+                                            s.cuda_stream))
+        st = mat.stats()
+        torch.cuda.synchronize()
+        assert st["sum_steps_p"] == ref["stats"]["sum_steps_p"] and st["n_hit"] == ref["stats"]["n_hit"]
+        for i, rt in enumerate(rts):
+            got = {"rgba": rt.color.cpu().numpy(), "depth": rt.depth.cpu().numpy(), "hit": rt.hit.cpu().numpy()}
+            assert_frame_equal(got, ref, f"frame {i}")
+
+
+@pytest.mark.parametrize("name", ["default_640x360", "default_src_depth_333x187", "stress13_200x112", "menger_closeup_320x180",
+                                  "fx_bounce_320x180", "edge_zero_steps_64x36", "edge_big_steps_2000_cap_96x54"])
+@pytest.mark.parametrize("host_path", [False, True])
+def test_step_count_plane_equals_oracle(oracle, torch_cuda, name, host_path):
+    """rm_blit_steps / rm_blit_steps_device: per-pixel evaluation counts of the primary and the shadow march
+    (ray.steps, cginc:37,387) equal the oracle's, the other planes are unchanged, the frame sums are rm_get_stats'"""
+    torch = torch_cuda
+    from raymarching_amd import Material
+    from raymarching_amd.material import _ptr, current_stream_handle
+    case = cases.BY_NAME[name]
+    ref = cases.oracle_run(case, oracle)
+    w, h = case.w, case.h
+    with Material() as mat:
+        src, sd = case.bind(mat)
+        if host_path:
+            rgba = np.zeros((h, w, 4), np.uint8); depth = np.zeros((h, w), np.float32); hit = np.zeros((h, w), np.uint8)
+            steps = np.zeros((h, w, 2), np.uint16)
+            mat._ck(mat._lib.rm_blit_steps(mat.handle, _ptr(src), _ptr(sd), _ptr(rgba), _ptr(depth), _ptr(hit), _ptr(steps), w, h))
+            st = mat.stats()
+        else:
+            dev = "cuda:0"
+            t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+            dsrc, dsd = t(src), t(sd)
+            rgba_t = torch.zeros((h, w, 4), dtype=torch.uint8, device=dev)
+            depth_t = torch.zeros((h, w), dtype=torch.float32, device=dev)
+            hit_t = torch.zeros((h, w), dtype=torch.uint8, device=dev)
+            steps_t = torch.zeros((h, w, 2), dtype=torch.int16, device=dev)
+            mat._ck(mat._lib.rm_blit_steps_device(mat.handle, _ptr(dsrc), _ptr(dsd), _ptr(rgba_t), _ptr(depth_t), _ptr(hit_t),
+                                                  _ptr(steps_t), w, h, current_stream_handle(dev)))
+            st = mat.stats()
+            torch.cuda.synchronize()
+            rgba, depth, hit = rgba_t.cpu().numpy(), depth_t.cpu().numpy(), hit_t.cpu().numpy()
+            steps = steps_t.cpu().numpy().view(np.uint16)
+    assert_frame_equal({"rgba": rgba, "depth": depth, "hit": hit}, ref, name)
+    assert np.array_equal(steps[..., 0], ref["steps_p"]), "primary step counts differ"
+    assert np.array_equal(steps[..., 1], ref["steps_s"]), "shadow step counts differ"
+    assert int(steps[..., 0].astype(np.int64).sum()) == st["sum_steps_p"] == ref["stats"]["sum_steps_p"]
+    assert int(steps[..., 1].astype(np.int64).sum()) == st["sum_steps_s"] == ref["stats"]["sum_steps_s"]
