@@ -142,6 +142,21 @@ int rm_blit_steps_device(rm_ctx *ctx, const void *d_src_rgba8, const void *d_sce
                          void *d_dst_rgba8, void *d_dst_depth, void *d_dst_hit, void *d_dst_steps,
                          int w, int h, void *hip_stream);
 
+/* rm_blit_device for callers that cannot allocate.  No counterpart in the reference: it is for code that must
+ * not call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.
+ * Same arguments, same output bytes as rm_blit_device, but the device memory the kernels work in beyond the
+ * caller's images (the persistent kernel's queue state, the counter slots, the reduced counters) is a static
+ * device array of 557 568 bytes that every GPU the library runs on holds until the process ends, instead of
+ * buffers the context allocates.  The call makes no hipMalloc/hipFree and creates no stream or event.
+ * Limits: at most 32768 blocks of 16x16 pixels (ceil(w/16)*ceil(h/16), e.g. 3840x2160), else RM_E_RANGE; a
+ * scene set with rm_set_primitives needs a table in allocated memory and is refused with RM_E_ARG.
+ * All contexts on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads)
+ * race; issue them in stream order.  The call leaves no event behind, so rm_get_stats after it waits on
+ * hip_stream, which must still exist then. */
+int rm_blit_device_noalloc(rm_ctx *ctx, const void *d_src_rgba8, const void *d_scene_depth,
+                           void *d_dst_rgba8, void *d_dst_depth, void *d_dst_hit,
+                           int w, int h, void *hip_stream);
+
 /* Row-band shard of one frame for multi-GPU rendering: renders the rows y of the
  * w x h frame with (y / band_rows) % n_parts == part into COMPACT buffers that
  * hold only those rows, in increasing y.  rm_band_rows() gives their count.

@@ -13,11 +13,13 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "rm_device.h"
 #include "rm_launch.h"
+#include "rm_scratch.h"
 
 namespace {
 
@@ -539,7 +541,7 @@ int ensure_partials(rm_ctx *c, WorkMem &M, unsigned slots) {
     return ensure_cap(c, M.partials, M.partials_cap, bytes);
 }
 
-size_t queue_words(uint32_t bm_cap) { return RM_Q_HDR + 3 * (size_t)RM_HEAVY_CAP + 3 * (size_t)bm_cap; }
+constexpr size_t queue_words(uint32_t bm_cap) { return RM_Q_HDR + 3 * (size_t)RM_HEAVY_CAP + 3 * (size_t)bm_cap; }
 
 // RM_OK, an error, or RM_FALLBACK_TILE when the persistent kernel cannot run this launch (its dynamic LDS does
 // not fit a workgroup) and the caller did not insist on it
@@ -660,6 +662,40 @@ WorkMem own_mem(rm_ctx *c) {
     WorkMem M;
     M.q = &c->q; M.partials = &c->d_partials; M.partials_cap = &c->d_partials_cap; M.stats = c->d_stats; M.fixed = false;
     return M;
+}
+
+// The static scratch array of one GPU carved into the same three pieces a context allocates for itself.  The
+// queue's host-side rotation state lives here, with the memory it describes: every context that uses the
+// entry point which allocates nothing on this GPU shares both.
+struct DeviceScratch {
+    bool ready = false;
+    QueueState q;
+    uint32_t *partials = nullptr; size_t partials_cap = 0;
+    unsigned long long *stats = nullptr;
+};
+std::mutex g_scratch_mu;
+DeviceScratch g_scratch[RM_SCRATCH_MAX_DEVICES];
+
+// the context's device must be current
+int device_scratch(rm_ctx *c, DeviceScratch **out) {
+    if (c->device >= RM_SCRATCH_MAX_DEVICES) return fail(c, RM_E_RANGE, "device index beyond the static scratch table");
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    DeviceScratch &D = g_scratch[c->device];
+    if (!D.ready) {
+        void *base = nullptr;
+        RM_HIP(c, rm_scratch_address(c->device, &base));
+        unsigned char *b = (unsigned char *)base;
+        D.q.buf = (uint32_t *)b;
+        D.q.cap_bytes = RM_SCRATCH_QUEUE_BYTES;
+        D.q.bm_cap = RM_SCRATCH_BM_WORDS;
+        D.q.dirty = true;                        // cleared, in stream order, by the first launch
+        D.partials = (uint32_t *)(b + RM_SCRATCH_QUEUE_BYTES);
+        D.partials_cap = RM_SCRATCH_SLOT_BYTES;
+        D.stats = (unsigned long long *)(b + RM_SCRATCH_QUEUE_BYTES + RM_SCRATCH_SLOT_BYTES);
+        D.ready = true;
+    }
+    *out = &D;
+    return RM_OK;
 }
 
 // `record`: leave an event behind the launch (every entry point but the one that allocates nothing)
@@ -908,6 +944,38 @@ int rm_blit_steps_device(rm_ctx *c, const void *d_src, const void *d_sdepth, voi
     RM_TRY
     if (!c) return RM_E_ARG;
     return blit_device_common(c, d_src, d_sdepth, d_rgba, d_depth, d_hit, d_steps, w, h, h > 0 ? h : 1, 0, 1, hip_stream);
+    RM_CATCH(c)
+}
+
+int rm_blit_device_noalloc(rm_ctx *c, const void *d_src, const void *d_sdepth, void *d_rgba, void *d_depth, void *d_hit,
+                           int w, int h, void *hip_stream) {
+    RM_TRY
+    if (!c) return RM_E_ARG;
+    int rc = check_size(c, w, h);
+    if (rc) return rc;
+    static_assert(queue_words(RM_SCRATCH_BM_WORDS) * 4 == RM_SCRATCH_QUEUE_BYTES, "scratch layout follows the queue layout");
+    const size_t slot_cap = RM_SCRATCH_SLOT_BYTES / (4 * (size_t)rm_slot_words());
+    if ((size_t)rm_tile_blocks(w, h, 1) > slot_cap)
+        return fail(c, RM_E_RANGE, "rm_blit_device_noalloc: frame beyond the static scratch (at most 32768 blocks of 16x16 pixels, "
+                                   "e.g. 3840x2160); use rm_blit_device");
+    if (!c->prims.empty())
+        return fail(c, RM_E_ARG, "rm_blit_device_noalloc: a primitive table lives in memory the library allocates; use rm_blit_device");
+    DeviceScope ds;
+    RM_HIP(c, ds.enter(c->device));
+    if ((rc = ensure_props(c))) return rc;
+    DeviceScratch *D = nullptr;
+    if ((rc = device_scratch(c, &D))) return rc;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    RmParams U;
+    if ((rc = build_params(c, &U, stream))) return rc;
+    U.w = w; U.h = h; U.rows = h;
+    U.band_rows = h; U.part = 0; U.n_parts = 1;
+    U.mode = RM_MODE_FRAG;
+    U.src = (const uint8_t *)d_src; U.sdepth = (const float *)d_sdepth;
+    U.dst_rgba = (uint8_t *)d_rgba; U.dst_depth = (float *)d_depth; U.dst_hit = (uint8_t *)d_hit;
+    WorkMem M;
+    M.q = &D->q; M.partials = &D->partials; M.partials_cap = &D->partials_cap; M.stats = D->stats; M.fixed = true;
+    return launch(c, U, stream, M, false);
     RM_CATCH(c)
 }
 

@@ -59,6 +59,7 @@ SYMBOLS = [
     ("rm_blit_device", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     ("rm_blit_steps", C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int]),
     ("rm_blit_steps_device", C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
+    ("rm_blit_device_noalloc", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     ("rm_band_rows", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     ("rm_blit_bands_device", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     ("rm_blit_poses_device", C.c_int, [_P, C.c_int, _FP, _FP, _FP, _P, _P, _P, C.c_int, C.c_int, _P]),
