@@ -1,31 +1,43 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Mrays/s (primary + shadow rays) of the sphere-tracing march on
-the reference's sample scene at 1920x1080 with the Raymarching.mat settings.
+"""Headline benchmark: Mrays/s (primary + soft-shadow rays) of the sphere-tracing march on the reference's
+sample scene with the Raymarching.mat settings, through the C ABI with every framebuffer resident in HBM.
 
     python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A step is one full frame per GPU through the C ABI (rm_blit_device) with the
-framebuffers resident in HBM.  With N > 1 every rank renders its own frame each step
-(pose sharding, weak scaling) and the finished frames are gathered to rank 0 with RCCL
-on a side stream, --gather-batch frames per collective, overlapped with the following
-renders; the timed region ends when every gather has landed.  Frames travel as RGB8
-(the blit's alpha is the constant 255): a rank
-finishes a 1080p frame every ~90 us, i.e. 70 GB/s of RGB8 towards the root, about what
-one xGMI link carries in one direction; RGBA8 would be 94 GB/s.  Rank 0 prints one JSON line.
+N = 1: a step is one 3840x2160 frame (rm_blit_device).  The JSON line carries the roofline of that frame's
+kernel (algorithmic flops / HIP-event time on the launch stream, HBM traffic from two rocprofv3 counter passes
+over a child run of this same frame), the CPU oracle timed on this host's cores, and secondary blocks: 1080p,
+a moving camera, two frames in flight, the 4K directional depth pass + frame, the 256-primitive stress scene,
+and the 64-pose 8K batch on one GPU (the one-GPU point of the scaling curve below).
+
+N > 1: strong scaling of the batched-pose configuration: a step is 64 orbit poses at 7680x4320, pose k on rank
+k mod N (rm_blit_poses_device), finished frames gathered to rank 0 over RCCL as compact tile records (only the
+8x8 tiles that hold a hit pixel travel; rank 0 expands them over the background into dense RGBA8 frames) on a
+side stream, overlapped with the rendering of the next batch.  The same line carries the time without the
+gather, and at N = 2 the 4K frame rendered as interleaved row bands with the directional depth pass.
 """
 from __future__ import annotations
 
 import argparse
+import glob
+import hashlib
 import json
 import os
+import shutil
+import sqlite3
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_VALU_TFLOPS = 157.3      # MI355X vector fp32 peak: 256 CU x 4 SIMD x 32 lanes x 2 (FMA) x 2 (packed) x 2.4 GHz
+N_POSES = 64                       # batched-pose configuration: 64 orbit cameras at 7680x4320
+POSE_W, POSE_H = 7680, 4320
+KERNEL_SOURCES = ("rm_kernels_common.h", "rm_math.h", "rm_device.h", "rm_k_queue.hip", "rm_k_tile.hip")
 
 
 def algorithmic_flops(st: dict) -> float:
@@ -34,39 +46,393 @@ def algorithmic_flops(st: dict) -> float:
     return 292.0 * st["sum_steps_p"] + 295.0 * st["sum_steps_s"] + 2152.0 * st["n_hit"]
 
 
-def cpu_baseline(w: int, h: int, props: dict) -> dict:
-    """The CPU oracle (a port: the reference has no CPU path) on this host's cores."""
+def kernel_source_sha() -> str:
+    h = hashlib.sha256()
+    for fn in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "raymarching_amd", "csrc", fn), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+# ---- HBM traffic: two rocprofv3 counter passes over a child run of the headline frame ------------------------------
+def pmc_child(args) -> None:
+    """what the counter passes profile: a few launches of the headline frame, nothing else"""
+    import torch
+    from raymarching_amd import Material, Raymarching, scenes
+    from raymarching_amd.material import _ptr, current_stream_handle
+    w, h, dev = args.width, args.height, "cuda:0"
+    torch.cuda.set_device(0)
+    mat = Material(device=0)
+    Raymarching(scenes.default_camera(w, h), mat, scenes.default_transforms()).bind()
+    mat.SetVector("_WorldSpaceLightPos0", scenes.WORLD_SPACE_LIGHT_POS0)
+    frame = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
+    depth = torch.empty((h, w), dtype=torch.float32, device=dev)
+    hit = torch.empty((h, w), dtype=torch.uint8, device=dev)
+    for _ in range(12):
+        mat._ck(mat._lib.rm_blit_device(mat.handle, None, None, _ptr(frame), _ptr(depth), _ptr(hit), w, h, current_stream_handle(dev)))
+    torch.cuda.synchronize()
+    mat.close()
+
+
+def measure_traffic(w: int, h: int) -> dict:
+    """HBM bytes per launch of the frame kernel = FETCH_SIZE + WRITE_SIZE (KB units), each from a rocprofv3 --pmc
+    pass of its own.  The frame reads at most 4 B per lane (no wide loads), so FETCH_SIZE is taken as it reads."""
+    if shutil.which("rocprofv3") is None:
+        return {"error": "rocprofv3 not found"}
+    out = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="rm_pmc_", dir="/tmp")
+        try:
+            cmd = ["rocprofv3", "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", "--width", str(w), "--height", str(h)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=150, capture_output=True, text=True)
+            dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return {"error": f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}"}
+            con = sqlite3.connect(dbs[0])
+            try:
+                rows = con.execute("select kernel_name, sum(value), count(distinct dispatch_id) from counters_collection "
+                                   "where counter_name = ? and (kernel_name like '%rm_queue_kernel%' or kernel_name like '%rm_tile_kernel%') "
+                                   "group by kernel_name order by 3 desc", (counter,)).fetchall()
+            finally:
+                con.close()
+            if not rows:
+                return {"error": f"no frame kernel in the {counter} pass"}
+            out[counter] = rows[0][1] / max(rows[0][2], 1) * 1024.0
+            out["kernel"] = rows[0][0]
+        except subprocess.TimeoutExpired:
+            return {"error": f"rocprofv3 --pmc {counter} timed out"}
+        except Exception as e:                                   # a profiler problem must not take the benchmark down
+            return {"error": f"{counter}: {type(e).__name__}: {e}"}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out["bytes"] = out["FETCH_SIZE"] + out["WRITE_SIZE"]
+    return out
+
+
+def committed_traffic(w: int, h: int):
+    """fallback: the counter passes kept under profiles/, only if they were taken from these kernel sources"""
+    path = os.path.join(ROOT, "profiles", "traffic_by_size.json")
+    if not os.path.exists(path):
+        return None, "no live counter pass and no profiles/traffic_by_size.json"
+    e = json.load(open(path)).get(f"{w}x{h}")
+    if not e:
+        return None, f"no committed counter pass for {w}x{h}"
+    if e.get("kernel_src_sha") != kernel_source_sha():
+        return None, f"profiles/traffic_by_size.json[{w}x{h}] was taken from other kernel sources (stale)"
+    return e.get("hbm_bytes_per_launch"), None
+
+
+# ---- CPU baseline ------------------------------------------------------------------------------------------------
+def cpu_baseline(props: dict) -> dict:
+    """The CPU oracle (a port: the reference has no CPU path) on this host's cores: 640x360 and 1920x1080, best of 5
+    after a warm-up, with every online CPU and with the box's CPU share (OMP_NUM_THREADS); the faster is reported."""
     from oracle import rm_oracle as O
-    threads = min(O.lib().rmo_online_cpus(), int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
+    online = O.lib().rmo_online_cpus()
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    counts = sorted({min(online, 256)} | ({min(share, online)} if share > 0 else set()))
     uni = O.Uniforms(props)
-    O.render(uni, w, h, threads=threads)                       # warm-up
-    best, st = None, None
-    for _ in range(5):
-        t0 = time.perf_counter()
-        out = O.render(uni, w, h, threads=threads)
-        dt = time.perf_counter() - t0
-        best = dt if best is None or dt < best else best
-        st = out["stats"]
-    rays = st["n_pixels"] + st["n_hit"]
-    return {"value": rays / best / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"one {w}x{h} frame of the same workload, best of 5 after 1 warm-up ({best * 1e3:.1f} ms)",
-            "tflops": algorithmic_flops(st) / best / 1e12}
+    res = {}
+    for (w, h) in ((640, 360), (1920, 1080)):
+        # the frustum corners carry the aspect ratio: both sizes are 16:9, like the bound camera
+        best = None
+        for threads in counts:
+            O.render(uni, w, h, threads=threads)                       # warm-up
+            tb, st = None, None
+            for _ in range(5):
+                t0 = time.perf_counter()
+                out = O.render(uni, w, h, threads=threads)
+                dt = time.perf_counter() - t0
+                tb = dt if tb is None or dt < tb else tb
+                st = out["stats"]
+            if best is None or tb < best[0]:
+                best = (tb, threads, st)
+        tb, threads, st = best
+        res[f"{w}x{h}"] = {"value": (st["n_pixels"] + st["n_hit"]) / tb / 1e6, "cores": threads, "ms": tb * 1e3,
+                           "tflops": algorithmic_flops(st) / tb / 1e12}
+    main = res["1920x1080"]
+    return {"value": main["value"], "unit": "Mrays/s", "cores": main["cores"], "kind": "port",
+            "host_cpus_online": online, "thread_counts_tried": counts,
+            "sample": f"one 1920x1080 frame of the same scene and settings, best of 5 after 1 warm-up ({main['ms']:.1f} ms); "
+                      f"640x360: {res['640x360']['value']:.1f} Mrays/s on {res['640x360']['cores']} threads ({res['640x360']['ms']:.1f} ms)",
+            "tflops": main["tflops"], "by_size": res}
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the RCCL gather of finished frames")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather-batch", type=int, default=8, help="frames per RCCL gather")
-    ap.add_argument("--force-gather", action="store_true", help="developer check: run the RCCL gather path with a single rank")
-    ap.add_argument("--kernel", type=int, default=0, help="kernel variant (0 = auto)")
-    args = ap.parse_args()
+# ---- helpers ---------------------------------------------------------------------------------------------------------
+class Frame:
+    """RGBA8 + depth + hit targets of n frames in HBM"""
 
+    def __init__(self, torch, dev, w, h, n=None, color=None):
+        shp = (h, w) if n is None else (n, h, w)
+        self.color = color if color is not None else torch.empty(shp + (4,), dtype=torch.uint8, device=dev)
+        self.depth = torch.empty(shp, dtype=torch.float32, device=dev)
+        self.hit = torch.empty(shp, dtype=torch.uint8, device=dev)
+
+
+def timed(torch, fn, steps, warmup, fence=None):
+    """W untimed + K timed calls of fn(i); returns (wall seconds, HIP-event ms per step on the current stream)"""
+    fence = fence or torch.cuda.synchronize
+    for i in range(warmup):
+        fn(i)
+    fence()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for i in range(steps):
+        fn(i)
+    e1.record()
+    fence()
+    el = time.perf_counter() - t0
+    return el, e0.elapsed_time(e1) / max(steps, 1)
+
+
+def pose_arrays(scenes, Raymarching, mat, ks, w, h):
+    import numpy as np
+    cams = [Raymarching(scenes.orbit_camera(k, N_POSES, w, h), mat, scenes.default_transforms()) for k in ks]
+    fcs = np.ascontiguousarray(np.stack([r.GetFrustumCorners().m for r in cams]), dtype=np.float32)
+    c2ws = np.ascontiguousarray(np.stack([r.cam.cameraToWorldMatrix.m for r in cams]), dtype=np.float32)
+    pos = np.ascontiguousarray(np.stack([r.cam.transform.position for r in cams]), dtype=np.float32)
+    return fcs, c2ws, pos
+
+
+def blit_poses(mat, fcs, c2ws, pos, fr, w, h, stream):
+    from raymarching_amd.material import _fp, _ptr
+    mat._ck(mat._lib.rm_blit_poses_device(mat.handle, len(pos), _fp(fcs), _fp(c2ws), _fp(pos), _ptr(fr.color), _ptr(fr.depth),
+                                          _ptr(fr.hit), w, h, stream))
+
+
+def rays(st):
+    return st["n_pixels"] + st["n_hit"]
+
+
+def block(st, ms, extra=None):
+    fl = algorithmic_flops(st)
+    out = {"ms_per_step": ms, "Mrays_per_s": rays(st) / (ms * 1e-3) / 1e6, "rays_per_step": rays(st),
+           "tflops": fl / (ms * 1e-3) / 1e12, "frac_of_peak": fl / (ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS}
+    out.update(extra or {})
+    return out
+
+
+# ---- N = 1 -------------------------------------------------------------------------------------------------------------
+def run_single(args) -> None:
+    traffic, traffic_err, traffic_src = None, None, None
+    if not args.no_traffic:
+        t = measure_traffic(args.width, args.height)          # child processes, before this process touches the GPU
+        if "bytes" in t:
+            traffic, traffic_src = t["bytes"], {"how": "live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over a child run of this frame",
+                                                "kernel": t["kernel"], "fetch_bytes": t["FETCH_SIZE"], "write_bytes": t["WRITE_SIZE"]}
+        else:
+            traffic_err = t["error"]
+    if traffic is None:
+        traffic, err2 = committed_traffic(args.width, args.height)
+        if traffic is not None:
+            traffic_src = {"how": "profiles/traffic_by_size.json (same kernel sources)", "live_error": traffic_err}
+        else:
+            traffic_err = f"{traffic_err}; {err2}" if traffic_err else err2
+            print(f"bench.py: WARNING: no HBM traffic figure: {traffic_err}", file=sys.stderr, flush=True)
+
+    import numpy as np
+    import torch
+    torch.cuda.set_device(0)
+    dev = "cuda:0"
+    from raymarching_amd import Material, Raymarching, ShadowMapDirectional, scenes
+    from raymarching_amd.material import _fp, _ptr, current_stream_handle
+    from raymarching_amd.unity import Transform, vec3
+
+    K, W = args.steps, args.warmup
+    w, h = args.width, args.height
+    stream = current_stream_handle(dev)
+
+    def default_material(ww, hh):
+        m = Material(device=0)
+        Raymarching(scenes.default_camera(ww, hh), m, scenes.default_transforms()).bind()
+        m.SetVector("_WorldSpaceLightPos0", scenes.WORLD_SPACE_LIGHT_POS0)
+        if args.kernel:
+            m.set_kernel(args.kernel)
+        return m
+
+    # ---- headline: one 3840x2160 frame per step, fixed pose -----------------------------------------------------
+    mat = default_material(w, h)
+    lib, ctx = mat._lib, mat.handle
+    fr = Frame(torch, dev, w, h)
+
+    def step(_i):
+        mat._ck(lib.rm_blit_device(ctx, None, None, _ptr(fr.color), _ptr(fr.depth), _ptr(fr.hit), w, h, stream))
+
+    elapsed, kernel_ms = timed(torch, step, K, W)
+    st = mat.stats()
+    flops = algorithmic_flops(st)
+    achieved = flops / (kernel_ms * 1e-3) / 1e12
+    evals = st["sum_steps_p"] + st["sum_steps_s"] + 7 * st["n_hit"]
+    out = {
+        "metric": "Mrays/s (primary+shadow)",
+        "value": rays(st) * K / elapsed / 1e6,
+        "unit": "Mrays/s",
+        "n_gpus": 1, "steps": K, "warmup": W,
+        "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"default SampleScene {w}x{h}, Raymarching.mat (_MaxSteps 400, _MaxDist 50, _StepFactor .7), "
+                               "primary + soft-shadow rays, one frame per step, fixed pose",
+                   "width": w, "height": h, "rays_per_frame": rays(st), "primary_rays": st["n_pixels"], "shadow_rays": st["n_hit"],
+                   "scene_evals_per_frame": evals, "parallelism": "single GPU"},
+        "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                     "traffic_error": None if traffic is not None else traffic_err,
+                     "algorithmic_bytes": 9.0 * st["n_pixels"],
+                     "flops_per_launch": flops, "kernel_ms": kernel_ms,
+                     "sum_steps_p": st["sum_steps_p"], "sum_steps_s": st["sum_steps_s"], "n_hit": st["n_hit"],
+                     "sdf_evals_per_s": evals / (kernel_ms * 1e-3),
+                     "framebuffer_GBps": (9.0 * st["n_pixels"]) / (kernel_ms * 1e-3) / 1e9,
+                     "kernel_src_sha": kernel_source_sha()},
+    }
+    props = None
+    if not args.no_cpu_baseline:
+        from oracle import rm_oracle as O
+        props = O.props_from_material(mat)
+
+    sec = {}
+    if not args.headline_only:
+        Ks, Ws = min(K, 50), min(W, 10)
+        # ---- moving camera at the headline size: a different orbit pose every step -------------------------------
+        n_orbit = 16
+        arr = [pose_arrays(scenes, Raymarching, mat, [k * (N_POSES // n_orbit)], w, h) for k in range(n_orbit)]
+        pose_rays, pose_flops = [], []
+        for fcs, c2ws, pos in arr:
+            mat._ck(lib.rm_set_matrix(ctx, b"_FrustrumCorners", _fp(fcs[0])))
+            mat._ck(lib.rm_set_matrix(ctx, b"_CameraInvViewMatrix", _fp(c2ws[0])))
+            mat._ck(lib.rm_set_vector(ctx, b"_WorldSpaceCameraPos", _fp(np.ascontiguousarray(np.append(pos[0], 0.0), dtype=np.float32))))
+            step(0)
+            s2 = mat.stats()
+            pose_rays.append(rays(s2)); pose_flops.append(algorithmic_flops(s2))
+        pos4 = [np.ascontiguousarray(np.append(a[2][0], 0.0), dtype=np.float32) for a in arr]
+
+        def step_orbit(i):
+            fcs, c2ws, _ = arr[i % n_orbit]
+            lib.rm_set_matrix(ctx, b"_FrustrumCorners", _fp(fcs[0]))
+            lib.rm_set_matrix(ctx, b"_CameraInvViewMatrix", _fp(c2ws[0]))
+            lib.rm_set_vector(ctx, b"_WorldSpaceCameraPos", _fp(pos4[i % n_orbit]))
+            step(i)
+
+        n_orb_steps = max(n_orbit, (Ks // n_orbit) * n_orbit)
+        el, ms = timed(torch, step_orbit, n_orb_steps, n_orbit)
+        tot_rays = sum(pose_rays) * (n_orb_steps // n_orbit)
+        tot_fl = sum(pose_flops) * (n_orb_steps // n_orbit)
+        sec["moving_camera_4k"] = {"what": f"{w}x{h}, {n_orbit} orbit poses in turn (SetMatrix x2 + SetVector + Blit per step): the tile "
+                                           "queue is ordered by the previous pose's costs",
+                                   "ms_per_step": el / n_orb_steps * 1e3, "Mrays_per_s": tot_rays / el / 1e6,
+                                   "tflops": tot_fl / (ms * n_orb_steps * 1e-3) / 1e12,
+                                   "frac_of_peak": tot_fl / (ms * n_orb_steps * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS}
+        mat.close()
+
+        # ---- 1920x1080 ------------------------------------------------------------------------------------------
+        m2 = default_material(1920, 1080)
+        f2 = Frame(torch, dev, 1920, 1080)
+
+        def step2(_i, m=m2, f=f2, s=stream):
+            m._ck(lib.rm_blit_device(m.handle, None, None, _ptr(f.color), _ptr(f.depth), _ptr(f.hit), 1920, 1080, s))
+
+        el, ms = timed(torch, step2, max(Ks, 20), Ws)
+        s2 = m2.stats()
+        sec["default_1080p"] = block(s2, ms, {"what": "default scene 1920x1080, one frame per step, fixed pose",
+                                              "ms_per_step_wall": el / max(Ks, 20) * 1e3})
+        # two frames in flight: two contexts on two streams, so one frame's long tail overlaps the next frame's bulk
+        m3 = default_material(1920, 1080)
+        f3 = Frame(torch, dev, 1920, 1080)
+        ss = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        pair = [(m2, f2, ss[0].cuda_stream), (m3, f3, ss[1].cuda_stream)]
+
+        def step_pair(_i):
+            for m, f, s in pair:
+                step2(0, m, f, s)
+
+        n2 = max(Ks, 20)
+        el, _ = timed(torch, step_pair, n2, Ws)
+        sec["default_1080p_two_in_flight"] = {"what": "the same 1080p frame from two contexts on two streams, frames_in_flight 2 (never the headline)",
+                                              "frames_in_flight": 2, "ms_per_frame": el / (2 * n2) * 1e3,
+                                              "Mrays_per_s": rays(s2) * 2 * n2 / el / 1e6,
+                                              "frac_of_peak": algorithmic_flops(s2) * 2 * n2 / el / 1e12 / PEAK_FP32_VALU_TFLOPS}
+        m2.close(); m3.close()
+        del f2, f3
+
+        # ---- 4K with the directional depth pass (configuration 3 on one GPU) ----------------------------------
+        m4 = default_material(w, h)
+        t = Transform(position=vec3(-3, 3, 9), rotation=scenes.shadow_camera().transform.rotation, lossyScale=vec3(14, 8, 1))
+        smd = ShadowMapDirectional(t, m4)
+        smd.Update()
+        corners = np.ascontiguousarray(np.stack(smd.corners).astype(np.float32).reshape(12))
+        fwd = np.ascontiguousarray(t.forward.astype(np.float32))
+        sm_depth = torch.empty((h, w), dtype=torch.float32, device=dev)
+
+        def step3(_i):
+            m4._ck(lib.rm_shadowmap_directional_device(m4.handle, _fp(corners), _fp(fwd), _ptr(sm_depth), None, w, h, stream))
+            m4._ck(lib.rm_blit_device(m4.handle, None, None, _ptr(fr.color), _ptr(fr.depth), _ptr(fr.hit), w, h, stream))
+
+        el, ms = timed(torch, step3, Ks, Ws)
+        m4._ck(lib.rm_shadowmap_directional_device(m4.handle, _fp(corners), _fp(fwd), _ptr(sm_depth), None, w, h, stream))
+        sd = m4.stats()
+        fl3 = flops + 292.0 * sd["sum_steps_p"]
+        sec["depth_pass_plus_frame_4k"] = {"what": f"{w}x{h} ShadowMapDirectional depth pass + frame, back to back per step",
+                                           "ms_per_step": ms, "Mrays_per_s": (rays(st) + sd["n_pixels"]) / (ms * 1e-3) / 1e6,
+                                           "tflops": fl3 / (ms * 1e-3) / 1e12, "frac_of_peak": fl3 / (ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS}
+        m4.close()
+        del sm_depth
+
+        # ---- stress scene: 256 primitives, 512 steps, 1080p (configuration 5) -----------------------------------
+        m5 = Material(device=0)
+        Raymarching(scenes.stress_camera(1920, 1080), m5, scenes.default_transforms()).bind()
+        m5.SetVector("_WorldSpaceLightPos0", scenes.WORLD_SPACE_LIGHT_POS0)
+        for k_, v_ in scenes.STRESS_FLOATS.items():
+            m5.SetFloat(k_, v_)
+        prims = scenes.stress_primitives(256)
+        m5.SetPrimitives(prims)
+        f5 = Frame(torch, dev, 1920, 1080)
+
+        def step5(_i):
+            m5._ck(lib.rm_blit_device(m5.handle, None, None, _ptr(f5.color), _ptr(f5.depth), _ptr(f5.hit), 1920, 1080, stream))
+
+        el, ms = timed(torch, step5, 3, 1)
+        s5 = m5.stats()
+        per_eval = sum(47 + (8, 19, 12, 15)[p["type"]] for p in prims) + 13 * (len(prims) - 1)
+        fl5 = (per_eval + 11.0) * s5["sum_steps_p"] + (per_eval + 14.0) * s5["sum_steps_s"] + s5["n_hit"] * (7.0 * per_eval + 36.0 * (len(prims) - 1) + 77.0)
+        sec["stress256_1080p"] = {"what": "256 smooth-union primitives (rotated, scaled), _MaxSteps 512, grazing camera, 1920x1080",
+                                  "ms_per_step": ms, "Mrays_per_s": rays(s5) / (ms * 1e-3) / 1e6, "flops_per_eval": per_eval,
+                                  "tflops": fl5 / (ms * 1e-3) / 1e12, "frac_of_peak": fl5 / (ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS}
+        m5.close()
+        del f5
+
+        # ---- 64 orbit poses at 7680x4320 on this one GPU: the N = 1 point of the strong-scaling curve ----------------
+        m6 = default_material(POSE_W, POSE_H)
+        per_call = 8
+        f6 = Frame(torch, dev, POSE_W, POSE_H, per_call)
+        batches = [pose_arrays(scenes, Raymarching, m6, list(range(b, b + per_call)), POSE_W, POSE_H) for b in range(0, N_POSES, per_call)]
+
+        def step6(_i):
+            for fcs, c2ws, pos in batches:
+                blit_poses(m6, fcs, c2ws, pos, f6, POSE_W, POSE_H, stream)
+
+        tot = {"n_pixels": 0, "n_hit": 0, "sum_steps_p": 0, "sum_steps_s": 0}
+        for fcs, c2ws, pos in batches:                       # untimed: the counters of every batch (also the warm-up)
+            blit_poses(m6, fcs, c2ws, pos, f6, POSE_W, POSE_H, stream)
+            s6 = m6.stats()
+            for k_ in tot:
+                tot[k_] += s6[k_]
+        el, ms = timed(torch, step6, 2, 0)
+        sec["poses_64x8k_one_gpu"] = block(tot, el / 2 * 1e3, {"what": f"{N_POSES} orbit poses at {POSE_W}x{POSE_H}, {per_call} per rm_blit_poses_device call, no gather: "
+                                                                       "what --gpus N > 1 runs, on one GPU"})
+        m6.close()
+        del f6
+    else:
+        mat.close()
+    out["secondary"] = sec
+    if props is not None:
+        out["cpu_baseline"] = cpu_baseline(props)
+    print(json.dumps(out), flush=True)
+
+
+# ---- N > 1 -------------------------------------------------------------------------------------------------------------
+def run_multi(args) -> None:
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -74,126 +440,199 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # before the first GPU call of this process
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
-    use_pg = world > 1 or args.force_gather
-    if use_pg:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    counts_group = dist.new_group(backend="gloo")               # record counts travel as host tensors
 
-    from raymarching_amd import Material, Raymarching, scenes
-    from raymarching_amd.distributed import PipelinedGather
-    from raymarching_amd.material import _ptr, current_stream_handle
+    from raymarching_amd import Material, Raymarching, ShadowMapDirectional, scenes
+    from raymarching_amd.distributed import TileGather, poses_of, render_frame_bands
+    from raymarching_amd.material import _fp, _ptr, current_stream_handle
+    from raymarching_amd.unity import Transform, vec3
 
-    w, h = args.width, args.height
+    K, W = args.steps, args.warmup
+    w, h = POSE_W, POSE_H
+    stream = current_stream_handle(dev)
     mat = Material(device=local_rank)
-    rm = Raymarching(scenes.default_camera(w, h), mat, scenes.default_transforms())
-    rm.bind()                                   # the SetMatrix block of OnRenderImage, once: the pose is fixed
+    Raymarching(scenes.default_camera(w, h), mat, scenes.default_transforms()).bind()
     mat.SetVector("_WorldSpaceLightPos0", scenes.WORLD_SPACE_LIGHT_POS0)
     if args.kernel:
         mat.set_kernel(args.kernel)
+    if rank == 0 and args.root_blocks_per_cu > 0:
+        # leave room on the root's CUs for the expansion kernels that run beside the rendering
+        mat.SetFloat("_RmBlocksPerCU", float(args.root_blocks_per_cu))
 
-    depth = torch.empty((h, w), dtype=torch.float32, device=dev)
-    hit = torch.empty((h, w), dtype=torch.uint8, device=dev)
-    frame = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)          # the blit's RGBA8 target
-    gather = (world > 1 and not args.no_gather) or args.force_gather
-    pipe = None
-    if gather:
-        assert (w * h) % 4 == 0, "RGB8 transport packs 4 pixels at a time"
-        pipe = PipelinedGather(torch.empty((h, w, 3), dtype=torch.uint8, device=dev), root=0, depth=2,
-                               single_rank_too=args.force_gather, batch=args.gather_batch)
-    lib, ctx = mat._lib, mat.handle
+    if N_POSES % world != 0:
+        raise SystemExit(f"{N_POSES} poses do not divide over {world} ranks")
+    mine = poses_of(N_POSES, rank, world)
+    per_rank = len(mine)
+    n_batches = max(1, min(args.pose_batches, per_rank))
+    per = (per_rank + n_batches - 1) // n_batches
+    groups = [mine[i:i + per] for i in range(0, per_rank, per)]          # the same split on every rank
+    tiles = ((w + 7) // 8) * ((h + 7) // 8)
+    # Rank 0 keeps every pose as a dense RGBA8 frame, ordered [rank that rendered it][its local index] so that one
+    # batch of one rank is contiguous: its own frames are rendered in place, the others are expanded in place.
+    dense = torch.empty((world, per_rank, h, w, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
+    frames = [Frame(torch, dev, w, h, len(g), color=(dense[0, b * per:b * per + len(g)] if rank == 0 else None))
+              for b, g in enumerate(groups)]
+    arrays = [pose_arrays(scenes, Raymarching, mat, g, w, h) for g in groups]
+    gather = TileGather(lambda fr, ht, rec, cnt: mat.compact_frames(fr, ht, rec, cnt), capacity_records=per * tiles, device=dev,
+                        root=0, count_group=counts_group, depth=2)
 
-    def step() -> None:
-        mat._ck(lib.rm_blit_device(ctx, None, None, _ptr(frame), _ptr(depth), _ptr(hit), w, h, current_stream_handle(dev)))
-        if pipe:
-            buf = pipe.acquire()            # slot of the current batch (stream-side wait when a new buffer is started)
-            mat.pack_rgb(frame, buf)        # RGBA8 -> RGB8 on the render stream (4 us; on the side stream it was slower:
-                                            # the extra events cost the host more than the kernel costs the GPU)
-            pipe.submit(buf)                # every gather_batch-th call: the collective, on the side stream
+    def on_received_for(b):
+        def on_received(p, records, n):
+            if p != 0:                                   # the root's own frames are dense already
+                mat.expand_frames(records, n, dense[p, b * per:b * per + len(groups[b])])
+        return on_received
 
-    def fence() -> None:
-        if pipe:
-            pipe.drain()
-        if use_pg:
-            dist.barrier()
+    pending = []
+
+    def render(b):
+        fcs, c2ws, pos = arrays[b]
+        blit_poses(mat, fcs, c2ws, pos, frames[b], w, h, stream)
+
+    def step_render(_i):
+        for b in range(len(groups)):
+            render(b)
+
+    def step_gather(_i):
+        for b in range(len(groups)):
+            render(b)
+            t = gather.submit(frames[b].color, frames[b].hit, tag=b)
+            if pending:                                  # the previous batch: its count is ready while this one renders
+                tp = pending.pop(0)
+                gather.complete(tp, on_received_for(tp.tag))
+            pending.append(t)
+
+    def fence_gather():
+        while pending:
+            tp = pending.pop(0)
+            gather.complete(tp, on_received_for(tp.tag))
+        gather.drain()
+        dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
-        step()
-    e1.record()
-    fence()
-    elapsed = time.perf_counter() - t0
-    st = mat.stats()
-    kernel_ms = e0.elapsed_time(e1) / args.steps        # launch stream: kernel + inter-launch gap
+    def fence():
+        dist.barrier()
+        torch.cuda.synchronize()
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    def reduce_max(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        cnt = torch.tensor([st["n_pixels"] + st["n_hit"]], dtype=torch.float64, device=dev)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        rays_per_step = float(cnt.item())
-    else:
-        rays_per_step = float(st["n_pixels"] + st["n_hit"])
+        return float(t.item())
+
+    # counters of this rank's share (untimed)
+    tot = np.zeros(4, dtype=np.float64)
+    for b in range(len(groups)):
+        render(b)
+        s = mat.stats()
+        tot += [s["n_pixels"], s["n_hit"], s["sum_steps_p"], s["sum_steps_s"]]
+    tt = torch.tensor(tot, dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+    st = dict(zip(["n_pixels", "n_hit", "sum_steps_p", "sum_steps_s"], [int(v) for v in tt.tolist()]))
+
+    el_r, _ = timed(torch, step_render, K, W, fence)
+    el_r = reduce_max(el_r)
+    el_g, _ = timed(torch, step_gather, K, W, fence_gather)
+    el_g = reduce_max(el_g)
+    sent = torch.tensor([float(gather.bytes_sent)], dtype=torch.float64, device=dev)
+    dist.all_reduce(sent, op=dist.ReduceOp.SUM)
+    sent_per_step = float(sent.item()) / (K + W)
+
+    sec = {}
+    if world == 2 and not args.headline_only:
+        # ---- configuration 3 on two GPUs: 3840x2160 as interleaved 8-row bands + the directional depth pass on both --------
+        bw, bh, band = 3840, 2160, 8
+        m3 = Material(device=local_rank)
+        Raymarching(scenes.default_camera(bw, bh), m3, scenes.default_transforms()).bind()
+        m3.SetVector("_WorldSpaceLightPos0", scenes.WORLD_SPACE_LIGHT_POS0)
+        t = Transform(position=vec3(-3, 3, 9), rotation=scenes.shadow_camera().transform.rotation, lossyScale=vec3(14, 8, 1))
+        smd = ShadowMapDirectional(t, m3)
+        smd.Update()
+        corners = np.ascontiguousarray(np.stack(smd.corners).astype(np.float32).reshape(12))
+        fwd = np.ascontiguousarray(t.forward.astype(np.float32))
+        sm_depth = torch.empty((bh, bw), dtype=torch.float32, device=dev)
+        rows = m3._lib.rm_band_rows(bh, band, rank, world)
+        c = torch.empty((rows, bw, 4), dtype=torch.uint8, device=dev)
+        d = torch.empty((rows, bw), dtype=torch.float32, device=dev)
+        hm = torch.empty((rows, bw), dtype=torch.uint8, device=dev)
+        rgb = torch.empty((rows, bw, 3), dtype=torch.uint8, device=dev)
+        recv = [torch.empty_like(rgb) for _ in range(world)] if rank == 0 else None
+
+        def step3(_i):
+            m3._ck(m3._lib.rm_shadowmap_directional_device(m3.handle, _fp(corners), _fp(fwd), _ptr(sm_depth), None, bw, bh, stream))
+            m3._ck(m3._lib.rm_blit_bands_device(m3.handle, None, None, _ptr(c), _ptr(d), _ptr(hm), bw, bh, band, rank, world, stream))
+            m3.pack_rgb(c, rgb)
+            dist.gather(rgb, recv, dst=0)
+
+        el3, _ = timed(torch, step3, min(K, 50), min(W, 10), fence)
+        el3 = reduce_max(el3)
+        s3 = m3.stats()
+        c3 = torch.tensor([float(rays(s3) + bw * bh / world)], dtype=torch.float64, device=dev)
+        dist.all_reduce(c3, op=dist.ReduceOp.SUM)
+        sec["bands_4k_with_depth_pass_2gpu"] = {"what": "3840x2160 frame as interleaved 8-row bands over 2 GPUs (rm_blit_bands_device) + the full directional "
+                                                        "depth pass on each + RCCL gather of the bands as RGB8, per step",
+                                                "ms_per_step": el3 / min(K, 50) * 1e3, "Mrays_per_s": float(c3.item()) * min(K, 50) / el3 / 1e6}
+        m3.close()
 
     if rank == 0:
         flops = algorithmic_flops(st)
-        achieved = flops / (kernel_ms * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("width") == w and tj.get("height") == h:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        spath = os.path.join(ROOT, "profiles", "traffic_by_size.json")
-        if traffic is None and os.path.exists(spath):
-            try:
-                traffic = json.load(open(spath)).get(f"{w}x{h}", {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         out = {
             "metric": "Mrays/s (primary+shadow)",
-            "value": rays_per_step * args.steps / elapsed / 1e6,
+            "value": rays(st) * K / el_g / 1e6,
             "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": el_g / K * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"default SampleScene {w}x{h}, Raymarching.mat (_MaxSteps 400, _MaxDist 50, _StepFactor .7), "
-                                   "primary + soft-shadow rays, one frame per GPU per step",
-                       "width": w, "height": h, "rays_per_frame": st["n_pixels"] + st["n_hit"],
-                       "primary_rays": st["n_pixels"], "shadow_rays": st["n_hit"],
-                       "scene_evals_per_frame": st["sum_steps_p"] + st["sum_steps_s"] + 7 * st["n_hit"],
-                       "parallelism": ("single GPU" if world == 1 else
-                                       f"pose-sharded x{world}" + (f", RCCL gather of RGB8 frames to rank 0, {args.gather_batch} frames per collective, overlapped with rendering" if gather else ", no gather"))},
-            "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
-                         "flops_per_launch": flops, "kernel_ms": kernel_ms,
-                         "sdf_evals_per_s": (st["sum_steps_p"] + st["sum_steps_s"] + 7 * st["n_hit"]) / (kernel_ms * 1e-3),
-                         "framebuffer_GBps": (9.0 * st["n_pixels"]) / (kernel_ms * 1e-3) / 1e9},
+            "config": {"workload": f"{N_POSES} orbit poses of the default SampleScene at {w}x{h} per step, Raymarching.mat settings, primary + "
+                                   "soft-shadow rays, pose k on rank k mod N, finished frames gathered to rank 0 as compact tile records "
+                                   "and expanded there into dense RGBA8 frames",
+                       "width": w, "height": h, "poses": N_POSES, "rays_per_step": rays(st), "primary_rays": st["n_pixels"],
+                       "shadow_rays": st["n_hit"], "pose_batches_per_rank": len(groups),
+                       "parallelism": f"pose-sharded x{world}, RCCL point-to-point gather of hit tiles to rank 0 on a side stream, overlapped with rendering",
+                       "gather_payload_bytes_per_step": sent_per_step,
+                       "dense_rgb8_bytes_per_step_if_not_compacted": 3.0 * w * h * (N_POSES - len(poses_of(N_POSES, 0, world)))},
+            "roofline": {"bound": "valu_fp32", "achieved": flops * K / el_g / 1e12, "peak": PEAK_FP32_VALU_TFLOPS * world, "unit": "TFLOP/s",
+                         "frac": flops * K / el_g / 1e12 / (PEAK_FP32_VALU_TFLOPS * world), "traffic": None,
+                         "flops_per_step": flops, "note": "whole job over all ranks, wall clock with the gather inside; per-kernel figures are the N = 1 line's"},
+            "no_gather": {"ms_per_step": el_r / K * 1e3, "value": rays(st) * K / el_r / 1e6,
+                          "what": "the same poses rendered, frames left on the rank that rendered them"},
+            "secondary": sec,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle import rm_oracle as O
-            out["cpu_baseline"] = cpu_baseline(w, h, O.props_from_material(mat))
         print(json.dumps(out), flush=True)
-
     mat.close()
-    if use_pg:
-        dist.destroy_process_group()
+    dist.destroy_process_group()
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=3840, help="N = 1 headline frame")
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--kernel", type=int, default=0, help="kernel variant (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 counter passes")
+    ap.add_argument("--headline-only", action="store_true", help="skip the secondary blocks (profiling runs)")
+    ap.add_argument("--pose-batches", type=int, default=2, help="N > 1: rm_blit_poses_device calls per rank and step")
+    ap.add_argument("--root-blocks-per-cu", type=int, default=3, help="N > 1: resident render blocks per CU on rank 0 (0 = all)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.pmc_child:
+        pmc_child(args)
+        return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if world == 1:
+        run_single(args)
+    else:
+        run_multi(args)
 
 
 if __name__ == "__main__":

@@ -203,6 +203,21 @@ int rm_shadowmap_directional_device(rm_ctx *ctx, const float corners[12], const 
 int rm_pack_rgb_device(rm_ctx *ctx, const void *d_rgba8, void *d_rgb8, size_t n_pixels, void *hip_stream);
 int rm_unpack_rgb_device(rm_ctx *ctx, const void *d_rgb8, void *d_rgba8, size_t n_pixels, void *hip_stream);
 
+/* Lossless compact transport: a finished frame differs from what the displaying GPU already holds (the constant
+ * _BackgroundColor, or the source image) only in the 8x8 tiles that contain a hit pixel.  rm_compact_frames_device
+ * appends one record of rm_tile_record_bytes() (= 196: tile index = frame * tiles_per_frame + ty * tiles_x + tx as
+ * uint32, then the tile's 64 pixels as RGB8, rows bottom-up) per such tile of the n_frames consecutive frames to
+ * d_records, in no particular order, and leaves their number in the uint32 *d_count (device memory, cleared by the
+ * call).  d_records must hold one record per tile in the worst case.  rm_expand_frames_device is the inverse on the
+ * receiving GPU: every frame is first set to d_src_rgba8 (or, if NULL, to this context's _BackgroundColor), then the
+ * records are written over it; the result equals the frames the blit wrote, byte for byte.  Both are asynchronous on
+ * hip_stream. */
+size_t rm_tile_record_bytes(void);
+int rm_compact_frames_device(rm_ctx *ctx, const void *d_rgba8, const void *d_hit, int w, int h, int n_frames,
+                             void *d_records, void *d_count, void *hip_stream);
+int rm_expand_frames_device(rm_ctx *ctx, const void *d_records, uint32_t n_records, const void *d_src_rgba8,
+                            void *d_dst_rgba8, int w, int h, int n_frames, void *hip_stream);
+
 /* ---- counters -------------------------------------------------------------
  * No counterpart in the reference (its nearest thing is the commented-out
  * step-count heat map, Assets/Raymarching.shader:203).  rm_get_stats waits for

@@ -21,6 +21,10 @@
 #include "rm_launch.h"
 #include "rm_scratch.h"
 
+// The event behind every launch only orders work of this GPU (the next launch on another stream, the counter
+// reduction); without the system-scope fence its record costs nothing measurable, with it 3 us per frame.
+#define RM_EVENT_FLAGS (hipEventDisableTiming | hipEventDisableSystemFence)
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -341,7 +345,7 @@ int ensure_device(rm_ctx *c) {
     int rc = ensure_props(c);
     if (rc) return rc;
     if (!c->stream) RM_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    if (!c->ev_last) RM_HIP(c, hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming));
+    if (!c->ev_last) RM_HIP(c, hipEventCreateWithFlags(&c->ev_last, RM_EVENT_FLAGS));
     if (!c->d_stats) RM_HIP(c, hipMalloc((void **)&c->d_stats, 4 * sizeof(unsigned long long)));
     c->dev_ready = true;
     return RM_OK;
@@ -1145,6 +1149,51 @@ int rm_pack_rgb_device(rm_ctx *c, const void *d_rgba8, void *d_rgb8, size_t n_pi
 int rm_unpack_rgb_device(rm_ctx *c, const void *d_rgb8, void *d_rgba8, size_t n_pixels, void *hip_stream) {
     RM_TRY
     return pack_common(c, d_rgb8, d_rgba8, n_pixels, true, hip_stream);
+    RM_CATCH(c)
+}
+
+size_t rm_tile_record_bytes(void) { return (size_t)rm_record_words() * 4; }
+
+int rm_compact_frames_device(rm_ctx *c, const void *d_rgba8, const void *d_hit, int w, int h, int n_frames,
+                             void *d_records, void *d_count, void *hip_stream) {
+    RM_TRY
+    if (!c) return RM_E_ARG;
+    if (!d_rgba8 || !d_hit || !d_records || !d_count || n_frames <= 0) return fail(c, RM_E_ARG, "rm_compact_frames_device: bad argument");
+    if (((uintptr_t)d_rgba8 | (uintptr_t)d_records | (uintptr_t)d_count) & 3u) return fail(c, RM_E_ARG, "rm_compact_frames_device: buffers must be 4-byte aligned");
+    int rc = check_size(c, w, h);
+    if (rc) return rc;
+    const unsigned long long tiles = (unsigned long long)((w + 7) / 8) * (unsigned long long)((h + 7) / 8) * (unsigned long long)n_frames;
+    if (tiles > 0x7fffffffull) return fail(c, RM_E_RANGE, "rm_compact_frames_device: more than 2^31 tiles in one call");
+    DeviceScope ds;
+    RM_HIP(c, ds.enter(c->device));
+    RM_HIP(c, rm_compact_tiles(d_rgba8, d_hit, w, h, (unsigned)n_frames, d_records, d_count, (hipStream_t)hip_stream));
+    return RM_OK;
+    RM_CATCH(c)
+}
+
+int rm_expand_frames_device(rm_ctx *c, const void *d_records, uint32_t n_records, const void *d_src_rgba8, void *d_dst_rgba8,
+                            int w, int h, int n_frames, void *hip_stream) {
+    RM_TRY
+    if (!c) return RM_E_ARG;
+    if (!d_dst_rgba8 || n_frames <= 0 || (n_records && !d_records)) return fail(c, RM_E_ARG, "rm_expand_frames_device: bad argument");
+    if (((uintptr_t)d_dst_rgba8 | (uintptr_t)d_records) & 3u) return fail(c, RM_E_ARG, "rm_expand_frames_device: buffers must be 4-byte aligned");
+    int rc = check_size(c, w, h);
+    if (rc) return rc;
+    DeviceScope ds;
+    RM_HIP(c, ds.enter(c->device));
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const size_t px = (size_t)w * (size_t)h;
+    if (d_src_rgba8) {
+        // miss pixels show _MainTex with the alpha the blit writes (fixed4(col, 1), shader:214)
+        if ((uintptr_t)d_src_rgba8 & 3u) return fail(c, RM_E_ARG, "rm_expand_frames_device: buffers must be 4-byte aligned");
+        RM_HIP(c, rm_fill_from_src(d_src_rgba8, d_dst_rgba8, px, (unsigned)n_frames, stream));
+    } else {
+        vec4 bg = getv(c, "_BackgroundColor");
+        const uint32_t bg8 = unorm8(bg[0]) | (unorm8(bg[1]) << 8) | (unorm8(bg[2]) << 16) | 0xFF000000u;
+        RM_HIP(c, hipMemsetD32Async((hipDeviceptr_t)d_dst_rgba8, (int)bg8, px * (size_t)n_frames, stream));
+    }
+    RM_HIP(c, rm_expand_tiles(d_records, n_records, w, h, (unsigned)n_frames, d_dst_rgba8, stream));
+    return RM_OK;
     RM_CATCH(c)
 }
 

@@ -19,6 +19,13 @@ unsigned rm_tile_blocks(int w, int rows, int n_poses);
 // RGBA8 -> RGB8 (unpack false: first argument in, second out) or RGB8 -> RGBA8 with alpha 255 (unpack true:
 // first argument is the RGB8 input, second the RGBA8 output); n_pixels must be a multiple of 4
 hipError_t rm_pack_rgb(const void *in, void *out, size_t n_pixels, bool unpack, hipStream_t stream);
+// Frame transport.  rm_compact_tiles appends one record of rm_record_words() dwords (tile index, 64 pixels as RGB8) per
+// 8x8 tile of the n_frames frames that holds a hit pixel and counts them in *counter (cleared first); rm_expand_tiles
+// writes such records back over frames that already hold the background.
+unsigned rm_record_words();
+hipError_t rm_compact_tiles(const void *rgba, const void *hit, int w, int h, unsigned n_frames, void *records, void *counter, hipStream_t stream);
+hipError_t rm_expand_tiles(const void *records, unsigned n_records, int w, int h, unsigned n_frames, void *rgba, hipStream_t stream);
+hipError_t rm_fill_from_src(const void *src_rgba8, void *dst_rgba8, size_t pixels_per_frame, unsigned n_frames, hipStream_t stream);
 hipError_t rm_reduce_stats(const unsigned *partials, unsigned n_blocks, unsigned long long *out, hipStream_t stream);
 
 // persistent tile-queue kernel: `blocks` workgroups of 256 threads.  With blocks_per_cu != nullptr

@@ -168,3 +168,117 @@ class PipelinedGather:
             self.i += self.batch - part
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.side)
+
+
+RECORD_WORDS = 49          # one compact-transport record: tile index + 64 pixels as RGB8 (rm_tile_record_bytes() / 4)
+
+
+class _Ticket:
+    __slots__ = ("slot", "n_frames", "count_dev", "count_host", "count_ready", "tag")
+
+
+class TileGather:
+    """Gathers finished frames to the root as compact tile records (rm_compact_frames_device): only the 8x8
+    tiles that hold a hit pixel travel, everything else the root reconstructs from the background it already
+    has (rm_expand_frames_device).  Record counts differ per rank and per batch, so the exchange is one small
+    count all-gather on `count_group` (host tensors: gloo) followed by point-to-point transfers of exactly
+    count records from every peer to the root (`group`: RCCL over xGMI on GPUs, each peer on its own link).
+
+        g = TileGather(compact, capacity_records, like_device, root=0)
+        t = g.submit(frames, hit)              # compaction on the current stream; returns at once
+        ... enqueue the next batch's rendering ...
+        g.complete(t, on_received)             # waits (host) for this batch's count, then transfers on a side
+                                               # stream; on the root on_received(rank, records, n) runs there
+        g.drain()
+
+    compact(frames, hit, records_out, count_out) must enqueue the compaction on the current stream.
+    """
+
+    def __init__(self, compact: Callable, capacity_records: int, device, root: int = 0, group=None, count_group=None,
+                 depth: int = 2):
+        self.compact, self.root, self.group = compact, root, group
+        self.count_group = count_group if count_group is not None else group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.side = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self.records = [torch.empty((capacity_records, RECORD_WORDS), dtype=torch.int32, device=self.device) for _ in range(depth)]
+        self.count_dev = [torch.zeros(1, dtype=torch.int32, device=self.device) for _ in range(depth)]
+        self.count_host = [torch.zeros(1, dtype=torch.int32).pin_memory() if self.cuda else torch.zeros(1, dtype=torch.int32)
+                           for _ in range(depth)]
+        self.free_ev = [None] * depth          # event: the transfer out of records[i] has finished
+        self.i = 0
+        self.bytes_sent = 0                    # payload bytes this rank has sent (diagnostics)
+        self.last_counts: Optional[List[int]] = None
+
+    def submit(self, frames: torch.Tensor, hit: torch.Tensor, tag=None) -> _Ticket:
+        k = self.i % len(self.records)
+        self.i += 1
+        if self.cuda and self.free_ev[k] is not None:
+            torch.cuda.current_stream(self.device).wait_event(self.free_ev[k])
+        self.compact(frames, hit, self.records[k], self.count_dev[k])
+        t = _Ticket()
+        t.slot, t.n_frames, t.tag = k, int(frames.shape[0]), tag
+        t.count_dev, t.count_host = self.count_dev[k], self.count_host[k]
+        if self.cuda:
+            t.count_host.copy_(t.count_dev, non_blocking=True)
+            t.count_ready = torch.cuda.Event()
+            t.count_ready.record()
+        else:
+            t.count_host.copy_(t.count_dev)
+            t.count_ready = None
+        return t
+
+    def complete(self, t: _Ticket, on_received: Optional[Callable[[int, torch.Tensor, int], None]] = None) -> List[int]:
+        """returns the record counts of all ranks for this batch"""
+        if t.count_ready is not None:
+            t.count_ready.synchronize()
+        mine = int(t.count_host.item())
+        counts = [torch.zeros(1, dtype=torch.int32) for _ in range(self.world)]
+        if self.world > 1:
+            dist.all_gather(counts, torch.tensor([mine], dtype=torch.int32), group=self.count_group)
+            counts = [int(c.item()) for c in counts]
+        else:
+            counts = [mine]
+        self.last_counts = counts
+        rec = self.records[t.slot]
+
+        def transfer():
+            ops, bufs = [], {}
+            if self.rank == self.root:
+                for p in range(self.world):
+                    if p != self.root and counts[p] > 0:
+                        bufs[p] = torch.empty((counts[p], RECORD_WORDS), dtype=torch.int32, device=self.device)
+                        ops.append(dist.P2POp(dist.irecv, bufs[p], self._global(p), group=self.group))
+            elif mine > 0:
+                ops.append(dist.P2POp(dist.isend, rec[:mine], self._global(self.root), group=self.group))
+                self.bytes_sent += mine * RECORD_WORDS * 4
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            if self.rank == self.root and on_received is not None:
+                for p in range(self.world):
+                    if p == self.root:
+                        on_received(p, rec, mine)
+                    else:
+                        on_received(p, bufs.get(p), counts[p])
+
+        if self.cuda:
+            ready = torch.cuda.Event()
+            ready.record()                      # everything enqueued so far, the compaction included
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ready)
+                transfer()
+                ev = torch.cuda.Event()
+                ev.record()
+                self.free_ev[t.slot] = ev
+        else:
+            transfer()
+        return counts
+
+    def _global(self, group_rank: int) -> int:
+        return dist.get_global_rank(self.group, group_rank) if self.group is not None else group_rank
+
+    def drain(self) -> None:
+        if self.cuda:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)

@@ -136,6 +136,23 @@ class Material:
         self._ck(self._lib.rm_unpack_rgb_device(self._ctx, _ptr(rgb), _ptr(rgba), n,
                                                 stream if stream is not None else current_stream_handle(rgba.device)))
 
+    def compact_frames(self, frames, hit, records, count, stream=None) -> None:
+        """device RGBA8 frames [n,h,w,4] + hit masks [n,h,w] -> compact tile records [cap,49] int32 and their number
+        (rm_compact_frames_device)"""
+        n, h, w = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
+        need = n * ((w + 7) // 8) * ((h + 7) // 8)
+        if records.numel() * records.element_size() < need * self._lib.rm_tile_record_bytes():
+            raise ValueError("record buffer smaller than one record per tile")
+        self._ck(self._lib.rm_compact_frames_device(self._ctx, _ptr(frames), _ptr(hit), w, h, n, _ptr(records), _ptr(count),
+                                                    stream if stream is not None else current_stream_handle(frames.device)))
+
+    def expand_frames(self, records, n_records: int, dst, src=None, stream=None) -> None:
+        """inverse of compact_frames into dst [n,h,w,4] on the GPU that displays the frames (rm_expand_frames_device)"""
+        n, h, w = int(dst.shape[0]), int(dst.shape[1]), int(dst.shape[2])
+        self._ck(self._lib.rm_expand_frames_device(self._ctx, _ptr(records) if n_records else None, int(n_records), _ptr(src),
+                                                   _ptr(dst), w, h, n,
+                                                   stream if stream is not None else current_stream_handle(dst.device)))
+
     def set_kernel(self, variant: int) -> None:
         self._ck(self._lib.rm_set_kernel(self._ctx, int(variant)))
 

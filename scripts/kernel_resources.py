@@ -56,6 +56,16 @@ def short_name(mangled: str) -> str:
     return f"{m.group(1)}<rot={m.group(2)}, scl={m.group(3)}>"
 
 
+def short_name_from_demangled(name: str) -> str:
+    """rm_queue_kernel4<rot=0, scl=0> from 'void (anonymous namespace)::rm_queue_kernel4<false, 0>(RmParams)'"""
+    m = re.search(r"(rm_[a-z_]+[4NF]?(?:_fx)?)(?:<(true|false), (\d)>)?", name)
+    if not m:
+        return name
+    if m.group(2) is None:
+        return m.group(1)
+    return f"{m.group(1)}<rot={1 if m.group(2) == 'true' else 0}, scl={m.group(3)}>"
+
+
 def main():
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raymarching_amd", "librmhip.so")
     for r in kernel_resources(lib):

@@ -42,7 +42,21 @@ def main():
                 f"from kernels where name = '{main_kernel}' limit 1")
     if kr:
         js["resources"] = dict(zip(["vgpr", "agpr", "sgpr", "lds", "scratch", "grid_x", "grid_y", "grid_z", "wg_x"], kr[0]))
-        lines.append(f"resources: {js['resources']}")
+        lines.append(f"resources as rocprofv3 records them: {js['resources']}")
+        # rocprofv3's vgpr/sgpr columns are not the allocation: the code object's own metadata (.vgpr_count, .sgpr_count)
+        # is what bounds occupancy (512 VGPRs per SIMD lane: 4 waves need <= 128)
+        try:
+            sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+            import kernel_resources as KR
+            lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raymarching_amd", "librmhip.so")
+            short = KR.short_name_from_demangled(main_kernel)
+            for r in KR.kernel_resources(lib):
+                if r["demangled"] == short:
+                    js["resources_elf"] = {"vgpr_count": int(r.get("vgpr_count", -1)), "sgpr_count": int(r.get("sgpr_count", -1)),
+                                           "scratch": int(r.get("private_segment_fixed_size", -1))}
+                    lines.append(f"resources in the code object's metadata (what occupancy follows): {js['resources_elf']}")
+        except Exception as e:
+            lines.append(f"(code-object metadata not read: {e})")
     counters = {}
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_grbm", "pmc_sq2", "pmc_tcp"):
         db = os.path.join(src, sub, "bench_results.db")
@@ -79,13 +93,16 @@ def main():
     open(dst + "_summary.txt", "w").write("\n".join(lines) + "\n")
     json.dump(js, open(dst + "_summary.json", "w"), indent=1, sort_keys=True)
     if "hbm_bytes_per_launch" in js:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        sha = bench.kernel_source_sha()
         json.dump({"width": w, "height": h, "kernel": main_kernel, "hbm_bytes_per_launch": js["hbm_bytes_per_launch"],
-                   "source": os.path.basename(dst) + "_summary.json"},
+                   "kernel_src_sha": sha, "source": os.path.basename(dst) + "_summary.json"},
                   open(os.path.join(os.path.dirname(dst) or ".", "traffic_latest.json"), "w"), indent=1)
         # one entry per frame size, so that bench.py can quote the counters for whichever size it runs
         by_size_path = os.path.join(os.path.dirname(dst) or ".", "traffic_by_size.json")
         by_size = json.load(open(by_size_path)) if os.path.exists(by_size_path) else {}
-        by_size[f"{w}x{h}"] = {"kernel": main_kernel, "hbm_bytes_per_launch": js["hbm_bytes_per_launch"],
+        by_size[f"{w}x{h}"] = {"kernel": main_kernel, "hbm_bytes_per_launch": js["hbm_bytes_per_launch"], "kernel_src_sha": sha,
                                "source": os.path.basename(dst) + "_summary.json"}
         json.dump(by_size, open(by_size_path, "w"), indent=1, sort_keys=True)
     print("\n".join(lines))

@@ -37,3 +37,45 @@ def assert_frame_close(got: dict, ref: dict, what: str = "") -> dict:
     assert depth_bad <= 1e-4 * n, f"{what}: {depth_bad} of {n} depths off by more than 1e-4 relative"
     assert col_bad <= 1e-3 * n, f"{what}: {col_bad} of {n} pixels off by more than 1/255"
     return {"mask_bad": mask_bad, "depth_bad": depth_bad, "col_bad": col_bad}
+
+
+# ---- compact frame transport, restated on the host for the tests (record layout of rm_compact_frames_device) ----
+RECORD_WORDS = 49
+
+
+def compact_frames_numpy(frames: np.ndarray, hit: np.ndarray) -> np.ndarray:
+    """frames [n,h,w,4] u8, hit [n,h,w] u8 -> records [T,49] int32 in tile order: tile index, then 64 pixels as RGB8"""
+    n, h, w = hit.shape
+    tx, ty = (w + 7) // 8, (h + 7) // 8
+    out = []
+    for f in range(n):
+        for j in range(ty):
+            for i in range(tx):
+                m = hit[f, j * 8:j * 8 + 8, i * 8:i * 8 + 8]
+                if not m.any():
+                    continue
+                px = np.zeros((8, 8, 3), dtype=np.uint8)
+                blk = frames[f, j * 8:j * 8 + 8, i * 8:i * 8 + 8, :3]
+                px[:blk.shape[0], :blk.shape[1]] = blk
+                rec = np.empty(RECORD_WORDS, dtype=np.uint32)
+                rec[0] = (f * ty + j) * tx + i
+                rec[1:] = px.reshape(-1).view("<u4")
+                out.append(rec)
+    return (np.stack(out) if out else np.zeros((0, RECORD_WORDS), dtype=np.uint32)).view(np.int32)
+
+
+def expand_frames_numpy(records: np.ndarray, n: int, h: int, w: int, background) -> np.ndarray:
+    """background: RGBA8 colour (4 bytes) or a source image [h,w,4]; returns frames [n,h,w,4] with alpha 255"""
+    bg = np.asarray(background, dtype=np.uint8)
+    frames = np.empty((n, h, w, 4), dtype=np.uint8)
+    frames[...] = bg
+    frames[..., 3] = 255
+    tx, ty = (w + 7) // 8, (h + 7) // 8
+    for rec in np.ascontiguousarray(records).view(np.uint32):
+        t = int(rec[0])
+        f, t2 = divmod(t, tx * ty)
+        j, i = divmod(t2, tx)
+        px = np.ascontiguousarray(rec[1:]).view(np.uint8).reshape(8, 8, 3)
+        hh, ww = min(8, h - j * 8), min(8, w - i * 8)
+        frames[f, j * 8:j * 8 + hh, i * 8:i * 8 + ww, :3] = px[:hh, :ww]
+    return frames

@@ -113,6 +113,44 @@ def _worker(rank, world, port, out_dir):
         if rank == 0:
             last = pipe.last_gathered()
             assert [[int(f[0, 0]) for f in t] for t in last] == [[30, 40], [31, 41]]
+        # ---- compact tile transport: hit tiles only, variable-size point-to-point gather -------------
+        from helpers import RECORD_WORDS, compact_frames_numpy, expand_frames_numpy
+        n_poses = 6
+        mine = D.poses_of(n_poses, rank, world)
+        rendered = [O.render(O.Uniforms(pose_props(k)), w, h, threads=1) for k in mine]
+        frames = torch.from_numpy(np.stack([r["rgba"] for r in rendered]))
+        hits = torch.from_numpy(np.stack([r["hit"] for r in rendered]))
+
+        def compact(fr, ht, records, count):
+            rec = compact_frames_numpy(fr.numpy(), ht.numpy())
+            records[: rec.shape[0]] = torch.from_numpy(rec)
+            count[0] = rec.shape[0]
+
+        tiles = ((w + 7) // 8) * ((h + 7) // 8)
+        tg = D.TileGather(compact, capacity_records=len(mine) * tiles, device="cpu", root=0)
+        bg = np.array([49, 77, 121, 255], dtype=np.uint8)          # unorm8 of the camera's background colour
+        delivered = {}
+
+        def on_received(p, records, n):
+            ids = D.poses_of(n_poses, p, world)
+            rec = records[:n].numpy() if n else np.zeros((0, RECORD_WORDS), dtype=np.int32)
+            out = expand_frames_numpy(rec, len(ids), h, w, bg)
+            for i, k in enumerate(ids):
+                delivered[k] = out[i]
+
+        for rep in range(2):                                        # twice: the record buffers rotate
+            delivered.clear()
+            t = tg.submit(frames, hits)
+            counts = tg.complete(t, on_received)
+            tg.drain()
+            assert len(counts) == world and all(0 < c < len(mine) * tiles for c in counts)
+            if rank == 0:
+                assert sorted(delivered) == list(range(n_poses))
+                for k in range(n_poses):
+                    ref = O.render(O.Uniforms(pose_props(k)), w, h, threads=2)["rgba"]
+                    assert np.array_equal(delivered[k], ref), f"pose {k} differs after the compact gather"
+            else:
+                assert not delivered and tg.bytes_sent == (rep + 1) * counts[rank] * RECORD_WORDS * 4
         open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()

@@ -462,3 +462,88 @@ def test_step_count_plane_equals_oracle(oracle, torch_cuda, name, host_path):
     assert np.array_equal(steps[..., 1], ref["steps_s"]), "shadow step counts differ"
     assert int(steps[..., 0].astype(np.int64).sum()) == st["sum_steps_p"] == ref["stats"]["sum_steps_p"]
     assert int(steps[..., 1].astype(np.int64).sum()) == st["sum_steps_s"] == ref["stats"]["sum_steps_s"]
+
+
+@pytest.mark.parametrize("name,with_src", [("default_640x360", False), ("default_src_depth_333x187", True),
+                                           ("edge_camera_inside_box_128x72", False), ("tiny_17x3", False),
+                                           ("orbit_k23_480x270", False)])
+def test_compact_transport_round_trip(torch_cuda, name, with_src):
+    """frame transport: compact (hit tiles only) -> expand over the background == the frame the blit wrote, byte for
+    byte; the records equal the host restatement's; covers a source image, a frame whose every pixel hits (camera
+    inside the box, where most tiles hit), ragged sizes and a batch of frames"""
+    torch = torch_cuda
+    from helpers import RECORD_WORDS, compact_frames_numpy, expand_frames_numpy
+    from raymarching_amd import Material
+    from raymarching_amd.material import _ptr, current_stream_handle
+    case = cases.BY_NAME[name]
+    dev = "cuda:0"
+    w, h, n = case.w, case.h, 3
+    with Material() as mat:
+        src, sd = case.bind(mat)
+        dsrc = torch.from_numpy(src).to(dev) if (src is not None and with_src) else None
+        frames = torch.zeros((n, h, w, 4), dtype=torch.uint8, device=dev)
+        hit = torch.zeros((n, h, w), dtype=torch.uint8, device=dev)
+        depth = torch.zeros((h, w), dtype=torch.float32, device=dev)
+        for f in range(n):
+            if f == 1:
+                mat.SetFloat("_MaxDist", 9.0 if name.startswith("default") else 4.0)      # a different frame in the middle
+            if f == 2:
+                mat.SetFloat("_MaxDist", 50.0)
+            mat._ck(mat._lib.rm_blit_device(mat.handle, _ptr(dsrc), None, _ptr(frames[f]), _ptr(depth), _ptr(hit[f]), w, h,
+                                            current_stream_handle(dev)))
+        tiles = ((w + 7) // 8) * ((h + 7) // 8) * n
+        records = torch.full((tiles, RECORD_WORDS), -1, dtype=torch.int32, device=dev)
+        count = torch.full((1,), 77, dtype=torch.int32, device=dev)
+        mat.compact_frames(frames, hit, records, count)
+        k = int(count.item())
+        want = compact_frames_numpy(frames.cpu().numpy(), hit.cpu().numpy())
+        assert k == want.shape[0]
+        got = records[:k].cpu().numpy().view(np.uint32)
+        order = np.argsort(got[:, 0], kind="stable")
+        assert np.array_equal(got[order], want.view(np.uint32)), "records differ from the host restatement"
+        back = torch.full_like(frames, 3)
+        mat.expand_frames(records, k, back, src=dsrc)
+        torch.cuda.synchronize()
+        assert torch.equal(back, frames), "compact -> expand is not the identity"
+        if with_src:
+            bg = src
+        else:
+            c = np.clip(mat.GetVector("_BackgroundColor")[:3].astype(np.float32), 0, 1)
+            bg = list(np.floor(c * np.float32(255) + np.float32(0.5)).astype(np.uint8)) + [255]
+        assert np.array_equal(expand_frames_numpy(want, n, h, w, bg), frames.cpu().numpy())
+
+
+@pytest.mark.parametrize("w,h", [(64, 40), (77, 13)])
+def test_compact_transport_all_hit_and_no_hit(torch_cuda, w, h):
+    """the two extremes on arbitrary pixels: every tile holds a hit (one record per tile, the expansion restores every
+    RGB byte) and no tile does (no record, the expansion is the background alone)"""
+    torch = torch_cuda
+    from helpers import RECORD_WORDS
+    from raymarching_amd import Material
+    dev, n = "cuda:0", 2
+    g = torch.Generator(device="cpu").manual_seed(11)
+    frames = torch.randint(0, 256, (n, h, w, 4), dtype=torch.uint8, generator=g).to(dev)
+    frames[..., 3] = 255
+    tiles = ((w + 7) // 8) * ((h + 7) // 8) * n
+    records = torch.zeros((tiles, RECORD_WORDS), dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    with Material() as mat:
+        hit = torch.ones((n, h, w), dtype=torch.uint8, device=dev)
+        mat.compact_frames(frames, hit, records, count)
+        assert int(count.item()) == tiles
+        assert sorted(records[:, 0].cpu().tolist()) == list(range(tiles))
+        back = torch.zeros_like(frames)
+        mat.expand_frames(records, tiles, back)
+        torch.cuda.synchronize()
+        assert torch.equal(back, frames)
+        hit.zero_()
+        hit[1, h - 1, w - 1] = 1                                       # one pixel in the last, ragged tile
+        mat.compact_frames(frames, hit, records, count)
+        assert int(count.item()) == 1 and int(records[0, 0].item()) == tiles - 1
+        hit.zero_()
+        mat.compact_frames(frames, hit, records, count)
+        assert int(count.item()) == 0
+        mat.SetVector("_BackgroundColor", [1.0, 0.5, 0.0, 1.0])
+        mat.expand_frames(records, 0, back)
+        torch.cuda.synchronize()
+        assert bool((back.view(-1, 4) == torch.tensor([255, 128, 0, 255], dtype=torch.uint8, device=dev)).all())
