@@ -482,9 +482,11 @@ def run_multi(args) -> None:
     gather = TileGather(lambda fr, ht, rec, cnt: mat.compact_frames(fr, ht, rec, cnt), capacity_records=per * tiles, device=dev,
                         root=0, count_group=counts_group, depth=2)
 
+    expand = [True]
+
     def on_received_for(b):
         def on_received(p, records, n):
-            if p != 0:                                   # the root's own frames are dense already
+            if p != 0 and expand[0]:                     # the root's own frames are dense already
                 mat.expand_frames(records, n, dense[p, b * per:b * per + len(groups[b])])
         return on_received
 
@@ -536,11 +538,15 @@ def run_multi(args) -> None:
 
     el_r, _ = timed(torch, step_render, K, W, fence)
     el_r = reduce_max(el_r)
+    expand[0] = False
+    el_t, _ = timed(torch, step_gather, K, W, fence_gather)
+    el_t = reduce_max(el_t)
+    expand[0] = True
     el_g, _ = timed(torch, step_gather, K, W, fence_gather)
     el_g = reduce_max(el_g)
     sent = torch.tensor([float(gather.bytes_sent)], dtype=torch.float64, device=dev)
     dist.all_reduce(sent, op=dist.ReduceOp.SUM)
-    sent_per_step = float(sent.item()) / (K + W)
+    sent_per_step = float(sent.item()) / (2 * (K + W))
 
     sec = {}
     if world == 2 and not args.headline_only:
@@ -599,6 +605,8 @@ def run_multi(args) -> None:
             "roofline": {"bound": "valu_fp32", "achieved": flops * K / el_g / 1e12, "peak": PEAK_FP32_VALU_TFLOPS * world, "unit": "TFLOP/s",
                          "frac": flops * K / el_g / 1e12 / (PEAK_FP32_VALU_TFLOPS * world), "traffic": None,
                          "flops_per_step": flops, "note": "whole job over all ranks, wall clock with the gather inside; per-kernel figures are the N = 1 line's"},
+            "transport_only": {"ms_per_step": el_t / K * 1e3, "value": rays(st) * K / el_t / 1e6,
+                               "what": "the gather without the expansion on rank 0: the tile records of every pose are resident in rank 0's HBM"},
             "no_gather": {"ms_per_step": el_r / K * 1e3, "value": rays(st) * K / el_r / 1e6,
                           "what": "the same poses rendered, frames left on the rank that rendered them"},
             "secondary": sec,
@@ -620,7 +628,9 @@ def main() -> None:
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 counter passes")
     ap.add_argument("--headline-only", action="store_true", help="skip the secondary blocks (profiling runs)")
     ap.add_argument("--pose-batches", type=int, default=2, help="N > 1: rm_blit_poses_device calls per rank and step")
-    ap.add_argument("--root-blocks-per-cu", type=int, default=3, help="N > 1: resident render blocks per CU on rank 0 (0 = all)")
+    ap.add_argument("--root-blocks-per-cu", type=int, default=0, help="N > 1: cap on resident render blocks per CU on rank 0 (0 = none; "
+                    "measured on one GPU: a cap does not make room for the expansion kernels, it only slows the rendering)")
+    ap.add_argument("--force-multi", action="store_true", help="developer check: run the N > 1 code path with a single rank")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child:
@@ -629,7 +639,7 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if world == 1:
+    if world == 1 and not args.force_multi:
         run_single(args)
     else:
         run_multi(args)
