@@ -106,6 +106,19 @@ int rm_get_matrix(rm_ctx *ctx, const char *name, float m[16]);
 /* Material.HasProperty: 1 if the march reads this name, 0 if it is only stored */
 int rm_has_property(rm_ctx *ctx, const char *name);
 
+/* Material.SetTexture for a texture that lives in HBM.  Replaces: mat.SetTexture("_ShadowMap", shadowMap.shadowMap),
+ * the binding Assets/Raymarching.cs:92 keeps commented out, for the `sampler2D _ShadowMap` the shader declares at
+ * Assets/Raymarching.shader:45.  d_texels: w x h fp32 depths as rm_shadowmap_render_device /
+ * rm_shadowmap_directional_device write them (row 0 = bottom), caller-owned, alive while blits read it; NULL unbinds.
+ * Other slot names are accepted and ignored (_MainTex and the camera depth texture are arguments of the blit).
+ * The map is read when _RmShadowMode is 1 (perspective map; bind _ShadowMapVPMatrix = projection * worldToCamera of
+ * the shadow camera, so that mul(_ShadowMapVPMatrix, float4(p,1)) is the clip-space position -- the commented line
+ * Assets/Raymarching.cs:93 writes the two factors in the other order) or 2 (directional map; bind the rectangle as
+ * _RmShadowMapCorners, rows TL,TR,BR,BL as Assets/ShadowMapDirectional.cs:11-16 orders them, and its
+ * _RmShadowMapForward).  The lookup takes the place of the soft-shadow march in frag (Assets/Raymarching.shader:195):
+ * 1 if the point is lit, 0 if the map holds something more than _RmShadowBias (relative, default 0.01) nearer. */
+int rm_set_texture_device(rm_ctx *ctx, const char *name, const void *d_texels, int w, int h);
+
 /* N-primitive scene (n = 0 returns to the 4-row matrices).  Extends
  * GetPositions/GetRotations/GetScales (Assets/Raymarching.cs:58-83); the tree is
  * the balanced pairwise smin of Assets/Raymarching.cginc:363 in index order (level by level,

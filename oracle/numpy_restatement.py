@@ -524,7 +524,70 @@ def pixel_rays(props, w, h):
     return rd
 
 
-def render(props, w, h, prims=None, src=None, scene_depth=None):
+def shadow_lookup(props, shadow_map, qx, qy, qz):
+    """What reads _ShadowMap / _ShadowMapVPMatrix (declared at shader:45-46, never read by the reference): 1 lit, 0 shadowed.
+    Mode 1: c = mul(VP, float4(q,1)), uv = c.xy/c.w*.5+.5, eye depth c.w against the stored r.length; mode 2: coordinates
+    along the edges of the ShadowMapDirectional rectangle and along its forward."""
+    mode = int(props["_RmShadowMode"])
+    sm = np.asarray(shadow_map, dtype=f)
+    sh, sw = sm.shape
+    with np.errstate(all="ignore"):
+        if mode == 1:
+            vp = props["_ShadowMapVPMatrix"]
+            r0, r1, r3 = row(vp, 0), row(vp, 1), row(vp, 3)
+            cx = ((r0[0] * qx + r0[1] * qy) + r0[2] * qz) + r0[3]
+            cy = ((r1[0] * qx + r1[1] * qy) + r1[2] * qz) + r1[3]
+            cw = ((r3[0] * qx + r3[1] * qy) + r3[2] * qz) + r3[3]
+            front = cw > 0
+            uu = (cx / cw) * f(.5) + f(.5)
+            vv = (cy / cw) * f(.5) + f(.5)
+            d = cw
+        else:
+            k = props["_RmShadowMapCorners"]
+            tl, br, bl = row(k, 0), row(k, 2), row(k, 3)
+            e1 = [br[j] - bl[j] for j in range(3)]
+            e2 = [tl[j] - bl[j] for j in range(3)]
+            fw = np.asarray(props["_RmShadowMapForward"], dtype=f)
+            rx, ry, rz = qx - bl[0], qy - bl[1], qz - bl[2]
+            uu = dot(rx, ry, rz, e1[0], e1[1], e1[2]) / dot(e1[0], e1[1], e1[2], e1[0], e1[1], e1[2])
+            vv = dot(rx, ry, rz, e2[0], e2[1], e2[2]) / dot(e2[0], e2[1], e2[2], e2[0], e2[1], e2[2])
+            d = dot(rx, ry, rz, fw[0], fw[1], fw[2])
+            front = np.ones(qx.shape, dtype=bool)
+        inside = front & (uu >= 0) & (uu < 1) & (vv >= 0) & (vv < 1)
+        ix = np.where(inside, np.floor(uu * f(sw)), 0).astype(np.int64)
+        iy = np.where(inside, np.floor(vv * f(sh)), 0).astype(np.int64)
+        ix, iy = np.minimum(ix, sw - 1), np.minimum(iy, sh - 1)
+        stored = sm[iy, ix]
+        dark = inside & (d > stored * (f(1) + f(props["_RmShadowBias"])))
+    return np.where(dark, f(0), f(1)).astype(f)
+
+
+def depth_pass(props, w, h, prims=None, corners=None, forward=None):
+    """The depth passes: raymarch() (cginc:367-392) along the rays of the bound camera (ShadowMap.Render, ShadowMap.cs:50-56)
+    or, with corners/forward, along `forward` from the rectangle of ShadowMapDirectional.cs:25-34; r.length is written."""
+    scene = Scene(props, prims)
+    n = w * h
+    if corners is None:
+        rdx, rdy, rdz = pixel_rays(props, w, h)
+        cam = np.asarray(props["_WorldSpaceCameraPos"], dtype=f)
+        ox, oy, oz = (np.full(n, cam[j], dtype=f) for j in range(3))
+    else:
+        c = np.asarray(corners, dtype=f).reshape(4, 3)                  # TL, TR, BR, BL
+        xs = (np.arange(w, dtype=f) + f(.5)) / f(w)
+        ys = (np.arange(h, dtype=f) + f(.5)) / f(h)
+        uu, vv = np.meshgrid(xs, ys)
+        uu, vv = uu.reshape(-1), vv.reshape(-1)
+        ox, oy, oz = [lerp(lerp(c[3][j], c[2][j], uu), lerp(c[0][j], c[1][j], uu), vv) for j in range(3)]
+        fw = np.asarray(forward, dtype=f)
+        rdx, rdy, rdz = (np.full(n, fw[j], dtype=f) for j in range(3))
+    steps = np.fmin(f(2000), f(props["_MaxSteps"]))
+    far = f(np.asarray(props["_ProjectionParams"], dtype=f)[2])
+    depth = np.fmin(np.full(n, far, dtype=f), f(props["_MaxDist"]))
+    hit, _, length, _ = march(scene, ox, oy, oz, rdx, rdy, rdz, depth, steps, f(props["_StepFactor"]))
+    return {"depth": length.reshape(h, w), "hit": hit.astype(np.uint8).reshape(h, w)}
+
+
+def render(props, w, h, prims=None, src=None, scene_depth=None, shadow_map=None):
     """shader:149-216 (frag) for every pixel.  Returns rgba u8 [h,w,4], depth, hit, stats."""
     scene = Scene(props, prims)
     n = w * h
@@ -603,7 +666,10 @@ def render(props, w, h, prims=None, src=None, scene_depth=None):
             sx, sy, sz = hx + (ux * contact) * f(2), hy + (uy * contact) * f(2), hz + (uz * contact) * f(2)
         sd = np.full(idx.size, sd_full, dtype=f)
         lx, ly, lz = (np.full(idx.size, L[j], dtype=f) for j in range(3))
-        _, evs, _, res = march(scene, sx, sy, sz, lx, ly, lz, sd, steps, sf, shadow=True)
+        if int(props.get("_RmShadowMode", 0)) != 0:
+            res, evs = shadow_lookup(props, shadow_map, sx, sy, sz), 0
+        else:
+            _, evs, _, res = march(scene, sx, sy, sz, lx, ly, lz, sd, steps, sf, shadow=True)
         ev_s[idx] = evs
         with np.errstate(all="ignore"):
             shadow = (res - f(0)) / (f(1) - f(0)) * (f(1) - f(.25)) + f(.25)                    # cginc:80-82

@@ -588,6 +588,38 @@ static inline float getshadow(const scene_ctx *c, f3 p, f3 n, float contact, int
     return res;
 }
 
+/* Shadow-map lookup in place of the shadow march (definition in rm_oracle.h; the reference declares _ShadowMap and
+ * _ShadowMapVPMatrix at shader:45-46 and never reads them).  Returns 1 (lit) or 0 (in shadow). */
+static inline float shadow_lookup(const scene_ctx *c, f3 p, f3 n, float contact) {
+    const rmo_uniforms *u = c->u;
+    f3 q = add3(p, scl3(scl3(n, contact), 2.0f));                    /* shader:107 */
+    float uu, vv, d;
+    if (u->shadow_mode == 1) {
+        f4 r0 = mrow(u->shadow_vp, 0), r1 = mrow(u->shadow_vp, 1), r3 = mrow(u->shadow_vp, 3);
+        float cx = ((r0.x * q.x + r0.y * q.y) + r0.z * q.z) + r0.w;
+        float cy = ((r1.x * q.x + r1.y * q.y) + r1.z * q.z) + r1.w;
+        float cw = ((r3.x * q.x + r3.y * q.y) + r3.z * q.z) + r3.w;
+        if (!(cw > 0.0f)) return 1.0f;
+        uu = (cx / cw) * .5f + .5f;
+        vv = (cy / cw) * .5f + .5f;
+        d = cw;
+    } else {
+        const float *k = u->shadow_corners;
+        f3 bl = v3(k[9], k[10], k[11]);
+        f3 e1 = sub3(v3(k[6], k[7], k[8]), bl), e2 = sub3(v3(k[0], k[1], k[2]), bl);
+        f3 r = sub3(q, bl);
+        uu = dot3(r, e1) / dot3(e1, e1);
+        vv = dot3(r, e2) / dot3(e2, e2);
+        d = dot3(r, v3(u->shadow_forward[0], u->shadow_forward[1], u->shadow_forward[2]));
+    }
+    if (!(uu >= 0.0f && uu < 1.0f && vv >= 0.0f && vv < 1.0f)) return 1.0f;
+    int ix = (int)floorf(uu * (float)u->shadow_w), iy = (int)floorf(vv * (float)u->shadow_h);
+    if (ix > u->shadow_w - 1) ix = u->shadow_w - 1;
+    if (iy > u->shadow_h - 1) iy = u->shadow_h - 1;
+    float stored = u->shadow_map[(size_t)iy * (size_t)u->shadow_w + (size_t)ix];
+    return d > stored * (1.0f + u->shadow_bias) ? 0.0f : 1.0f;
+}
+
 /* ---- shader:125-127  getAO ------------------------------------------------ */
 static inline float getAO(const scene_ctx *c, f3 n) {
     float s = c->u->normal_sample_scale;
@@ -697,7 +729,8 @@ static void frag_pixel(job_t *j, int x, int y, rmo_stats *st) {
         }
         f4 s = scene(c, hitpoint);                                    /* shader:193 */
         f3 srgb = xyz(s);
-        float shadow = remap(getshadow(c, hitpoint, normal, r.contact, &sev), 0.0f, 1.0f, .25f, 1.0f);
+        float sh = u->shadow_mode != 0 ? shadow_lookup(c, hitpoint, normal, r.contact) : getshadow(c, hitpoint, normal, r.contact, &sev);
+        float shadow = remap(sh, 0.0f, 1.0f, .25f, 1.0f);
         float ndl = dot3(normal, c->light) * .5f + .5f;
         f3 shaded = scl3(scl3(scl3(srgb, ndl), shadow), getAO(c, rawnormal));
         if (u->fx_debug_view == 1) shaded = v3(shadow, shadow, shadow);                                    /* shader:200 */

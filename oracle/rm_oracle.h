@@ -85,6 +85,25 @@ typedef struct {
     int32_t domain_op;
     float domain_period[3];
     float domain_size;
+    /* Shadow-map consumption.  The reference declares `sampler2D _ShadowMap; float4x4 _ShadowMapVPMatrix;`
+     * (Raymarching.shader:45-46), has the binding commented out (Raymarching.cs:91-93) and no code that samples the
+     * map, so the lookup is this build's definition (parity unpinned by the reference):
+     *   0  the shader as it stands: getshadow() marches (shader:102-123)
+     *   1  perspective map (the ShadowMap.Render pass): c = mul(_ShadowMapVPMatrix, float4(q,1)); the point is lit
+     *      unless c.w > 0, uv = c.xy / c.w * .5 + .5 lies in [0,1)^2 and c.w > map[uv] * (1 + bias)
+     *      (c.w is the eye depth the depth pass stores as r.length)
+     *   2  directional map (the ShadowMapDirectional pass): r = q - BL; u = dot(r,e1)/dot(e1,e1), v = dot(r,e2)/dot(e2,e2)
+     *      with e1 = BR - BL, e2 = TL - BL, d = dot(r, forward); lit unless uv in [0,1)^2 and d > map[uv] * (1 + bias)
+     * q = hitpoint + normal * _ContactThreshold * 2, the point getshadow() starts from (shader:107); the map is
+     * point-sampled at texel (floor(u*w), floor(v*h)), row 0 = bottom; the result (1 lit, 0 shadowed) takes the
+     * place of getshadow()'s in frag (shader:195). */
+    int32_t shadow_mode;
+    const float *shadow_map;     /* shadow_w x shadow_h depths (r.length of a depth pass) */
+    int32_t shadow_w, shadow_h;
+    float shadow_vp[16];         /* _ShadowMapVPMatrix, column-major like every matrix here */
+    float shadow_corners[12];    /* directional: TL,TR,BR,BL as ShadowMapDirectional.cs:11-16 orders them */
+    float shadow_forward[3];
+    float shadow_bias;
 } rmo_uniforms;
 
 /* scene() bodies.  PRIMS is the reference's active code (cginc:336-363).  The fractal bodies are

@@ -32,7 +32,10 @@ class RmoUniforms(C.Structure):
                 ("scene_body", C.c_int32), ("fractal_scale", C.c_float), ("fractal_rotation", C.c_float * 3),
                 ("fractal_power", C.c_float), ("fx_step_heat", C.c_int32), ("fx_debug_view", C.c_int32),
                 ("fx_volumetric", C.c_int32), ("fx_bounce", C.c_int32),
-                ("domain_op", C.c_int32), ("domain_period", C.c_float * 3), ("domain_size", C.c_float)]
+                ("domain_op", C.c_int32), ("domain_period", C.c_float * 3), ("domain_size", C.c_float),
+                ("shadow_mode", C.c_int32), ("shadow_map", C.POINTER(C.c_float)), ("shadow_w", C.c_int32), ("shadow_h", C.c_int32),
+                ("shadow_vp", C.c_float * 16), ("shadow_corners", C.c_float * 12), ("shadow_forward", C.c_float * 3),
+                ("shadow_bias", C.c_float)]
 
 
 class RmoStats(C.Structure):
@@ -126,7 +129,8 @@ def fp(a: np.ndarray):
 class Uniforms:
     """Owns an RmoUniforms and the primitive array it may point to."""
 
-    def __init__(self, props: dict, prims: Optional[Sequence[dict]] = None, shade_miss_pixels: bool = False):
+    def __init__(self, props: dict, prims: Optional[Sequence[dict]] = None, shade_miss_pixels: bool = False,
+                 shadow_map: Optional[np.ndarray] = None):
         u = RmoUniforms()
         u.frustum_corners[:] = f32(props["_FrustrumCorners"]).tolist()
         u.cam_inv_view[:] = f32(props["_CameraInvViewMatrix"]).tolist()
@@ -173,6 +177,18 @@ class Uniforms:
         u.domain_size = props.get("_RmDomainSize", 1.0)
         u.fractal_rotation[:] = [props.get("_FractalRotationX", 0.0), props.get("_FractalRotationY", 0.0),
                                  props.get("_FractalRotationZ", 0.0)]
+        u.shadow_mode = int(props.get("_RmShadowMode", 0))
+        u.shadow_bias = props.get("_RmShadowBias", 0.01)
+        u.shadow_vp[:] = f32(props.get("_ShadowMapVPMatrix", np.eye(4))).tolist()
+        u.shadow_corners[:] = f32(props.get("_RmShadowMapCorners", np.zeros(16)))[[0, 4, 8, 1, 5, 9, 2, 6, 10, 3, 7, 11]].tolist()
+        u.shadow_forward[:] = f32(props.get("_RmShadowMapForward", np.zeros(4)))[:3].tolist()
+        self._shadow_map = None
+        if u.shadow_mode != 0:
+            if shadow_map is None:
+                raise ValueError("_RmShadowMode set but no shadow map given")
+            self._shadow_map = np.ascontiguousarray(shadow_map, dtype=np.float32)
+            u.shadow_map = self._shadow_map.ctypes.data_as(C.POINTER(C.c_float))
+            u.shadow_h, u.shadow_w = self._shadow_map.shape
         self.u = u
 
     @property
@@ -180,11 +196,12 @@ class Uniforms:
         return C.byref(self.u)
 
 
-PROP_MATRICES = ("_FrustrumCorners", "_CameraInvViewMatrix", "_Positions", "_Rotations", "_Scales")
-PROP_VECTORS = ("_WorldSpaceCameraPos", "_WorldSpaceLightPos0", "_ProjectionParams", "_BackgroundColor", "_RmDomainPeriod")
+PROP_MATRICES = ("_FrustrumCorners", "_CameraInvViewMatrix", "_Positions", "_Rotations", "_Scales", "_ShadowMapVPMatrix",
+                 "_RmShadowMapCorners")
+PROP_VECTORS = ("_WorldSpaceCameraPos", "_WorldSpaceLightPos0", "_ProjectionParams", "_BackgroundColor", "_RmDomainPeriod", "_RmShadowMapForward")
 PROP_FLOATS = ("_MaxSteps", "_MaxDist", "_StepFactor", "_ContactThreshold", "_NormalSampleScale",
                "_FractalScale", "_FractalRotationX", "_FractalRotationY", "_FractalRotationZ", "_RmSceneBody", "_RmFractalPower",
-               "_RmStepHeat", "_RmDebugView", "_RmVolumetricLight", "_RmBounce", "_RmDomainOp", "_RmDomainSize")
+               "_RmStepHeat", "_RmDebugView", "_RmVolumetricLight", "_RmBounce", "_RmDomainOp", "_RmDomainSize", "_RmShadowMode", "_RmShadowBias")
 
 
 def props_from_material(mat) -> dict:

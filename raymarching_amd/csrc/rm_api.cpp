@@ -48,6 +48,8 @@ const char *const kDeclared[] = {
     // lines of frag that the reference keeps commented out: col += r.steps/100*_StepFactor (shader:203), the
     // alternative outputs (:198-201), the light integration along the ray (:206-212), the bounce loop (:178-187)
     "_RmStepHeat", "_RmDebugView", "_RmVolumetricLight", "_RmBounce",
+    // shadow-map lookup in place of the shadow march: what reads _ShadowMap / _ShadowMapVPMatrix (shader:45-46)
+    "_RmShadowMode", "_RmShadowBias", "_RmShadowMapCorners", "_RmShadowMapForward",
 };
 
 typedef std::array<float, 4> vec4;
@@ -87,6 +89,7 @@ struct rm_ctx {
     std::vector<rm_primitive> prims;
     bool prims_dirty = false;
     int kernel = RM_KERNEL_AUTO;
+    const float *shadow_map = nullptr; int shadow_w = 0, shadow_h = 0;      // _ShadowMap: caller-owned device depth plane
 
     hipStream_t stream = nullptr;           // used by the host-pointer entry points and by rm_get_stats
     hipEvent_t ev_last = nullptr;           // recorded behind every launch of the allocating entry points
@@ -198,6 +201,11 @@ void load_defaults(rm_ctx *c) {
     c->floats["_RmDebugView"] = 0.0f;
     c->floats["_RmVolumetricLight"] = 0.0f;
     c->floats["_RmBounce"] = 0.0f;
+    c->floats["_RmShadowMode"] = 0.0f;
+    c->floats["_RmShadowBias"] = 0.01f;
+    c->matrices["_ShadowMapVPMatrix"] = mat_identity();
+    c->matrices["_RmShadowMapCorners"] = mat_identity();
+    c->vectors["_RmShadowMapForward"] = {0, 0, 1, 0};
     c->floats["_RmDomainOp"] = 0.0f;
     c->floats["_RmDomainSize"] = 1.0f;              // default b of boxfold (cginc:156) and R of spherefold (cginc:161)
     c->vectors["_RmDomainPeriod"] = {0, 0, 0, 0};
@@ -495,6 +503,23 @@ int build_params(rm_ctx *c, RmParams *U, hipStream_t stream) {
                   (getf(c, "_RmBounce", 0.0f) != 0.0f ? RM_FX_BOUNCE : 0u);
     U->fx_view = (int32_t)getf(c, "_RmDebugView", 0.0f);
     if (U->fx_view < 0 || U->fx_view > 3) return fail(c, RM_E_ARG, "_RmDebugView must be 0..3");
+    U->shadow_mode = (int32_t)getf(c, "_RmShadowMode", 0.0f);
+    if (U->shadow_mode < 0 || U->shadow_mode > 2) return fail(c, RM_E_ARG, "_RmShadowMode must be 0 (march), 1 (perspective map) or 2 (directional map)");
+    if (U->shadow_mode != 0) {
+        if (!c->shadow_map) return fail(c, RM_E_ARG, "_RmShadowMode is set but no _ShadowMap is bound (rm_set_texture_device)");
+        U->shadow_map = c->shadow_map; U->sm_w = c->shadow_w; U->sm_h = c->shadow_h;
+        const mat4 vp = getm(c, "_ShadowMapVPMatrix");
+        get_row(vp, 0, U->sm_row0); get_row(vp, 1, U->sm_row1); get_row(vp, 3, U->sm_row3);
+        const mat4 k = getm(c, "_RmShadowMapCorners");            // rows TL, TR, BR, BL (Assets/ShadowMapDirectional.cs:11-16)
+        float tl[4], br[4], bl[4];
+        get_row(k, 0, tl); get_row(k, 2, br); get_row(k, 3, bl);
+        for (int i = 0; i < 3; i++) { U->sm_bl[i] = bl[i]; U->sm_e1[i] = br[i] - bl[i]; U->sm_e2[i] = tl[i] - bl[i]; }
+        U->sm_n1 = U->sm_e1[0] * U->sm_e1[0] + U->sm_e1[1] * U->sm_e1[1] + U->sm_e1[2] * U->sm_e1[2];
+        U->sm_n2 = U->sm_e2[0] * U->sm_e2[0] + U->sm_e2[1] * U->sm_e2[1] + U->sm_e2[2] * U->sm_e2[2];
+        const vec4 f = getv(c, "_RmShadowMapForward");
+        U->sm_fwd[0] = f[0]; U->sm_fwd[1] = f[1]; U->sm_fwd[2] = f[2];
+        U->sm_onebias = 1.0f + getf(c, "_RmShadowBias", 0.01f);
+    }
     U->dom_op = (int32_t)getf(c, "_RmDomainOp", 0.0f);
     if (U->dom_op < RM_DOM_NONE || U->dom_op > RM_DOM_SPHEREFOLD) return fail(c, RM_E_ARG, "_RmDomainOp must be 0..3");
     const vec4 period = getv(c, "_RmDomainPeriod");
@@ -718,6 +743,7 @@ int launch(rm_ctx *c, const RmParams &U, hipStream_t stream, WorkMem M, bool rec
     if (U.body != RM_BODY_PRIMS && kernel == RM_KERNEL_STREAM) kernel = RM_KERNEL_QUEUE;      // no stream kernel for the fractal bodies
     if (U.mode == RM_MODE_FRAG && (U.fx_flags != 0 || U.fx_view != 0)) kernel = RM_KERNEL_TILE;   // the optional frag lines exist in the tile kernels only
     if (U.dom_op != RM_DOM_NONE) kernel = RM_KERNEL_TILE;                                          // and so do the domain operators
+    if (U.mode == RM_MODE_FRAG && U.shadow_mode != 0) kernel = RM_KERNEL_TILE;                     // and the shadow-map lookup
     if (U.dst_steps) kernel = RM_KERNEL_TILE;                                                      // and the per-pixel step-count plane
     int rc = order_after_last(c, stream);
     if (rc) return rc;
@@ -867,6 +893,18 @@ int rm_has_property(rm_ctx *c, const char *name) {
     if (!c || !name) return 0;
     for (const char *d : kDeclared) if (std::strcmp(d, name) == 0) return 1;
     return 0;
+    RM_CATCH(c)
+}
+
+int rm_set_texture_device(rm_ctx *c, const char *name, const void *d_texels, int w, int h) {
+    RM_TRY
+    if (!c || !name) return fail(c, RM_E_ARG, "rm_set_texture_device: null argument");
+    if (std::strcmp(name, "_ShadowMap") != 0) return RM_OK;       // other texture slots are stored nowhere: the blit takes _MainTex and the depth texture as arguments
+    if (d_texels && (w <= 0 || h <= 0 || w > 32768 || h > 32768)) return fail(c, RM_E_ARG, "rm_set_texture_device: bad size");
+    if ((uintptr_t)d_texels & 3u) return fail(c, RM_E_ARG, "rm_set_texture_device: the depth plane must be 4-byte aligned");
+    c->shadow_map = (const float *)d_texels;
+    c->shadow_w = d_texels ? w : 0; c->shadow_h = d_texels ? h : 0;
+    return RM_OK;
     RM_CATCH(c)
 }
 

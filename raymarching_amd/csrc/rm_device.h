@@ -143,6 +143,15 @@ struct RmParams {
     int32_t  fx_view;          // 1 shadow (shader:200), 2 normal*.5+.5 (:201), 3 clamp(scene(hitpoint).r*2.5-1.75,0,1) (:198)
     // domain operator applied to p at the top of scene() (functions the reference defines and never calls);
     // tile kernels with the optional lines only
+    // shadow-map lookup in place of the shadow march (tile kernels with the optional lines only): the reference declares
+    // _ShadowMap and _ShadowMapVPMatrix (shader:45-46) and never reads them
+    int32_t  shadow_mode;      // 0 march (shader:102-123), 1 perspective map, 2 directional map
+    int32_t  sm_w, sm_h;
+    const float *shadow_map;   // sm_w x sm_h depths written by a depth pass (r.length)
+    float    sm_row0[4], sm_row1[4], sm_row3[4];   // rows x, y, w of _ShadowMapVPMatrix
+    float    sm_bl[3], sm_e1[3], sm_e2[3], sm_fwd[3];   // directional: BL, BR - BL, TL - BL, forward
+    float    sm_n1, sm_n2;     // dot(e1,e1), dot(e2,e2)
+    float    sm_onebias;       // 1 + _RmShadowBias
     int32_t  dom_op;           // RM_DOM_*
     float    dom_period[3];    // m of shmod (cginc:94-99) per axis; <= 0: axis left alone
     float    dom_size;         // b of boxfold (cginc:156) / R of spherefold (cginc:161)

@@ -232,6 +232,34 @@ RM_DI V3 rm_normal_raw(const RmParams &U, const S &sc, V3 hp) {
     return raw;
 }
 
+// Shadow-map lookup that takes getshadow()'s place when U.shadow_mode != 0: 1 = lit, 0 = in shadow.  q is the point
+// getshadow() would start from (shader:107).  Perspective map: c = mul(_ShadowMapVPMatrix, float4(q,1)), uv = c.xy/c.w*.5+.5,
+// eye depth c.w against the stored r.length; directional map: coordinates along the rectangle's edges and its forward.
+RM_DI float rm_shadow_lookup(const RmParams &U, V3 p, V3 n, float contact) {
+    const V3 q = mk3(p.x + (n.x * contact) * 2.0f, p.y + (n.y * contact) * 2.0f, p.z + (n.z * contact) * 2.0f);
+    float uu, vv, d;
+    if (U.shadow_mode == 1) {
+        const float cx = ((U.sm_row0[0] * q.x + U.sm_row0[1] * q.y) + U.sm_row0[2] * q.z) + U.sm_row0[3];
+        const float cy = ((U.sm_row1[0] * q.x + U.sm_row1[1] * q.y) + U.sm_row1[2] * q.z) + U.sm_row1[3];
+        const float cw = ((U.sm_row3[0] * q.x + U.sm_row3[1] * q.y) + U.sm_row3[2] * q.z) + U.sm_row3[3];
+        if (!(cw > 0.0f)) return 1.0f;
+        uu = (cx / cw) * .5f + .5f;
+        vv = (cy / cw) * .5f + .5f;
+        d = cw;
+    } else {
+        const V3 r = mk3(q.x - U.sm_bl[0], q.y - U.sm_bl[1], q.z - U.sm_bl[2]);
+        uu = rm_dot3(r, mk3(U.sm_e1[0], U.sm_e1[1], U.sm_e1[2])) / U.sm_n1;
+        vv = rm_dot3(r, mk3(U.sm_e2[0], U.sm_e2[1], U.sm_e2[2])) / U.sm_n2;
+        d = rm_dot3(r, mk3(U.sm_fwd[0], U.sm_fwd[1], U.sm_fwd[2]));
+    }
+    if (!(uu >= 0.0f && uu < 1.0f && vv >= 0.0f && vv < 1.0f)) return 1.0f;
+    int ix = (int)floorf(uu * (float)U.sm_w), iy = (int)floorf(vv * (float)U.sm_h);
+    ix = ix > U.sm_w - 1 ? U.sm_w - 1 : ix;
+    iy = iy > U.sm_h - 1 ? U.sm_h - 1 : iy;
+    const float stored = U.shadow_map[(size_t)iy * (size_t)U.sm_w + (size_t)ix];
+    return d > stored * U.sm_onebias ? 0.0f : 1.0f;
+}
+
 template <class S>
 RM_DI PixelOut rm_compute_pixel_fx(const RmParams &U, const S &sc, int x, int yl, int pose,
                                    unsigned &c_hit, unsigned &c_p, unsigned &c_s) {
@@ -272,7 +300,9 @@ RM_DI PixelOut rm_compute_pixel_fx(const RmParams &U, const S &sc, int x, int yl
         }
         V4 s = sc.full(hp);
         int sev = 0;
-        float sh = rm_getshadow(sc, hp, n, L, r.contact, U.shadow_depth, U.n_steps, sf, sev);
+        float sh;
+        if (U.shadow_mode != 0) sh = rm_shadow_lookup(U, hp, n, r.contact);
+        else sh = rm_getshadow(sc, hp, n, L, r.contact, U.shadow_depth, U.n_steps, sf, sev);
         c_s += (unsigned)sev;
         if (r.hit) {                                           // the bounced ray may have missed: then tex stays
             float shadow = sh * 0.75f + .25f;

@@ -80,6 +80,19 @@ class Material:
         a = np.ascontiguousarray(m.m if isinstance(m, Matrix4x4) else np.asarray(m, dtype=_F).reshape(16), dtype=_F)
         self._ck(self._lib.rm_set_matrix(self._ctx, name.encode(), _fp(a)))
 
+    def SetTexture(self, name: str, tex) -> None:
+        """Material.SetTexture for a device-resident fp32 plane [h,w] (a RenderTexture's depth, or a tensor); only
+        `_ShadowMap` is read by the march (rm_set_texture_device).  None unbinds."""
+        t = getattr(tex, "depth", tex)
+        if t is None:
+            self._ck(self._lib.rm_set_texture_device(self._ctx, name.encode(), None, 0, 0))
+            return
+        if isinstance(t, np.ndarray):
+            raise ValueError("SetTexture takes a device-resident plane")
+        self._textures = getattr(self, "_textures", {})
+        self._textures[name] = t                                  # keeps the plane alive while it is bound
+        self._ck(self._lib.rm_set_texture_device(self._ctx, name.encode(), _ptr(t), int(t.shape[1]), int(t.shape[0])))
+
     def GetFloat(self, name: str) -> float:
         v = C.c_float()
         self._ck(self._lib.rm_get_float(self._ctx, name.encode(), C.byref(v)))

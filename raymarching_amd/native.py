@@ -54,6 +54,7 @@ SYMBOLS = [
     ("rm_get_vector", C.c_int, [_P, C.c_char_p, _FP]),
     ("rm_get_matrix", C.c_int, [_P, C.c_char_p, _FP]),
     ("rm_has_property", C.c_int, [_P, C.c_char_p]),
+    ("rm_set_texture_device", C.c_int, [_P, C.c_char_p, _P, C.c_int, C.c_int]),
     ("rm_set_primitives", C.c_int, [_P, C.POINTER(RmPrimitive), C.c_int]),
     ("rm_blit", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int]),
     ("rm_blit_device", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),

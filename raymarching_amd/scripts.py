@@ -36,10 +36,11 @@ def get_frustum_corners(cam: Camera) -> Matrix4x4:
 class Raymarching:
     """Assets/Raymarching.cs: binds five matrices and blits (OnRenderImage, :85-95)."""
 
-    def __init__(self, cam: Camera, mat: Material, transforms: Sequence[Optional[Transform]]):
+    def __init__(self, cam: Camera, mat: Material, transforms: Sequence[Optional[Transform]], shadowMap=None):
         self.cam = cam
         self.mat = mat
         self.transforms: List[Optional[Transform]] = list(transforms)
+        self.shadowMap = shadowMap            # a ShadowMap or ShadowMapDirectional; None = the script as it stands
 
     def GetFrustumCorners(self) -> Matrix4x4:
         return get_frustum_corners(self.cam)
@@ -78,8 +79,30 @@ class Raymarching:
         self.mat.SetVector("_ProjectionParams", [1.0, near, far, F(1) / far])
         self.mat.SetVector("_BackgroundColor", list(self.cam.backgroundColor[:3]) + [1.0])
 
+    def bind_shadow_map(self) -> None:
+        """The three lines OnRenderImage keeps commented out (Raymarching.cs:91-93): render the shadow map, bind it as
+        `_ShadowMap`, bind the matrix that takes a world position into it.  For a ShadowMap camera that is
+        `_ShadowMapVPMatrix` = projection * worldToCamera (the commented line writes the factors in the other order, which
+        is not a transform of positions); for a ShadowMapDirectional rectangle its corners and forward."""
+        sm = self.shadowMap
+        sm.Render()
+        self.mat.SetTexture("_ShadowMap", sm.shadowMap)
+        if isinstance(sm, ShadowMap):
+            self.mat.SetMatrix("_ShadowMapVPMatrix", sm.cam.projectionMatrix * sm.cam.worldToCameraMatrix)
+            self.mat.SetFloat("_RmShadowMode", 1.0)
+        else:
+            k = Matrix4x4.identity()
+            for i in range(4):
+                k.SetRow(i, sm.corners[i])
+            self.mat.SetMatrix("_RmShadowMapCorners", k)
+            self.mat.SetVector("_RmShadowMapForward", sm.transform.forward)
+            self.mat.SetFloat("_RmShadowMode", 2.0)
+
     def OnRenderImage(self, src: Optional[RenderTexture], dest: RenderTexture, scene_depth=None) -> None:
         self.bind()
+        if self.shadowMap is not None:
+            self.bind_shadow_map()
+            self.bind()                       # the shadow pass may share this material: put the main camera back
         Graphics.Blit(src, dest, self.mat, scene_depth=scene_depth)
 
 

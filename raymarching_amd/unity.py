@@ -112,6 +112,18 @@ class Matrix4x4:
     def from_rows(rows) -> "Matrix4x4":
         return Matrix4x4(np.asarray(rows, dtype=F).reshape(4, 4).T.reshape(16))
 
+    def __mul__(self, other: "Matrix4x4") -> "Matrix4x4":
+        """Matrix4x4 operator*: the matrix product, accumulated in float32 left to right"""
+        a, b = self.as_rows(), other.as_rows()
+        out = np.zeros((4, 4), dtype=F)
+        for i in range(4):
+            for j in range(4):
+                acc = F(0)
+                for k in range(4):
+                    acc = F(acc + a[i, k] * b[k, j])
+                out[i, j] = acc
+        return Matrix4x4.from_rows(out)
+
     @staticmethod
     def TRS(pos, q, scale) -> "Matrix4x4":
         cols = [quat_rotate(q, vec3(1, 0, 0)) * F(scale[0]),
@@ -161,3 +173,23 @@ class Camera:
         rows = m.as_rows()
         rows[:, 2] = -rows[:, 2]
         return Matrix4x4.from_rows(rows)
+
+    @property
+    def worldToCameraMatrix(self) -> Matrix4x4:
+        """inverse of cameraToWorldMatrix (a rotation, a translation and the Z flip): R^T and -R^T t"""
+        rows = self.cameraToWorldMatrix.as_rows().astype(np.float64)
+        r, t = rows[:3, :3], rows[:3, 3]
+        out = np.zeros((4, 4), dtype=np.float64)
+        out[:3, :3] = r.T
+        out[:3, 3] = -(r.T @ t)
+        out[3, 3] = 1.0
+        return Matrix4x4.from_rows(out.astype(F))
+
+    @property
+    def projectionMatrix(self) -> Matrix4x4:
+        """Camera.projectionMatrix: OpenGL-convention perspective matrix (clip.w = -z_view = eye depth)"""
+        t = math.tan(math.radians(float(self.fieldOfView)) * 0.5)
+        n, fa = float(self.nearClipPlane), float(self.farClipPlane)
+        rows = [[1.0 / (t * float(self.aspect)), 0, 0, 0], [0, 1.0 / t, 0, 0],
+                [0, 0, -(fa + n) / (fa - n), -2.0 * fa * n / (fa - n)], [0, 0, -1, 0]]
+        return Matrix4x4.from_rows(np.asarray(rows, dtype=F))

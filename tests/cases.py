@@ -53,12 +53,65 @@ def synthetic_depth(w: int, h: int) -> np.ndarray:
     return d
 
 
+def light_camera(sw: int, sh: int):
+    """a shadow camera 20 units from the objects towards the light (_WorldSpaceLightPos0), looking back at them"""
+    from raymarching_amd.unity import Camera, quat_look_rotation
+    centre = np.array([-3.0, 0.5, 0.5])
+    L = scenes.WORLD_SPACE_LIGHT_POS0[:3].astype(np.float64)
+    pos = centre + 20.0 * L
+    return Camera(transform=Transform(position=pos.astype(F), rotation=quat_look_rotation(centre - pos)), fieldOfView=50.0,
+                  aspect=sw / sh, nearClipPlane=0.3, farClipPlane=1000.0)
+
+
+def light_rectangle() -> Transform:
+    """the ShadowMapDirectional rectangle: 24 x 14 units, 20 units from the objects towards the light, facing them"""
+    from raymarching_amd.unity import quat_look_rotation
+    centre = np.array([-3.0, 0.5, 0.5])
+    L = scenes.WORLD_SPACE_LIGHT_POS0[:3].astype(np.float64)
+    pos = centre + 20.0 * L
+    return Transform(position=pos.astype(F), rotation=quat_look_rotation(centre - pos), lossyScale=vec3(24, 14, 1))
+
+
 class Case:
-    def __init__(self, name, w, h, kind="frag", setup=None, prims=None, src=False, sdepth=False, heavy=False):
+    def __init__(self, name, w, h, kind="frag", setup=None, prims=None, src=False, sdepth=False, heavy=False, shadow=None):
         self.name, self.w, self.h, self.kind = name, w, h, kind
         self._setup, self.prims, self.use_src, self.use_sdepth, self.heavy = setup, prims, src, sdepth, heavy
         self.corners = None
         self.forward = None
+        # frag cases that read a shadow map instead of marching the shadow ray: ("persp" | "dir", map width, map height)
+        self.shadow = shadow
+
+    def bind_shadow_pass(self, mat: Material):
+        """binds `mat` (already bound for the frame) for the depth pass that feeds this case's shadow map; returns what the
+        pass needs beyond the material: (corners, forward) for the directional pass, None for the perspective one"""
+        kind, sw, sh = self.shadow
+        if kind == "persp":
+            sm = ShadowMap(light_camera(sw, sh), mat)
+            mat.SetMatrix("_FrustrumCorners", sm.GetFrustumCorners())
+            mat.SetMatrix("_CameraInvViewMatrix", sm.cam.cameraToWorldMatrix)
+            mat.SetVector("_WorldSpaceCameraPos", sm.cam.transform.position)
+            return None
+        smd = ShadowMapDirectional(light_rectangle(), mat)
+        smd.Update()
+        return np.stack(smd.corners).astype(F).reshape(12), smd.transform.forward.astype(F)
+
+    def bind_shadow_lookup(self, mat: Material) -> None:
+        """what Raymarching.cs:92-93 would bind next to the texture itself"""
+        kind, sw, sh = self.shadow
+        if kind == "persp":
+            cam = light_camera(sw, sh)
+            mat.SetMatrix("_ShadowMapVPMatrix", cam.projectionMatrix * cam.worldToCameraMatrix)
+            mat.SetFloat("_RmShadowMode", 1.0)
+        else:
+            smd = ShadowMapDirectional(light_rectangle(), mat)
+            smd.Update()
+            from raymarching_amd.unity import Matrix4x4
+            k = Matrix4x4.identity()
+            for i in range(4):
+                k.SetRow(i, smd.corners[i])
+            mat.SetMatrix("_RmShadowMapCorners", k)
+            mat.SetVector("_RmShadowMapForward", smd.transform.forward)
+            mat.SetFloat("_RmShadowMode", 2.0)
 
     def bind(self, mat: Material):
         """applies the case to a material; returns (src, scene_depth)"""
@@ -246,6 +299,13 @@ CASES = [
     Case("fx_heat_bounce_stress13_160x90", 160, 90, setup=_fx({"_RmBounce": 1.0, "_RmStepHeat": 1.0}, inner=_stress),
          prims=scenes.stress_primitives(13, seed=0x5EED000D)),
     Case("fx_bounce_view_menger_160x90", 160, 90, setup=_fx({"_RmBounce": 1.0, "_RmDebugView": 2.0}, inner=_fractal(1, True))),
+    # the shadow map read in the frame pass instead of the soft-shadow march (what _ShadowMap/_ShadowMapVPMatrix are for)
+    Case("shadowmap_lookup_persp_320x180", 320, 180, shadow=("persp", 512, 512)),
+    Case("shadowmap_lookup_dir_320x180", 320, 180, shadow=("dir", 640, 384)),
+    Case("shadowmap_lookup_dir_transformed_bounce_200x112", 200, 112, shadow=("dir", 300, 200),
+         setup=_fx({"_RmBounce": 1.0, "_RmShadowBias": 0.03}, inner=_transformed(False))),
+    Case("shadowmap_lookup_persp_stress13_lowres_160x90", 160, 90, shadow=("persp", 64, 48), setup=_stress,
+         prims=scenes.stress_primitives(13, seed=0x5EED000D)),
     Case("shadow_persp_100x100", 100, 100, kind="shadow_persp", setup=_shadow_persp),
     Case("shadow_dir_256x144", 256, 144, kind="shadow_dir", setup=_shadow_dir),
     # domain operators in front of scene()
@@ -271,7 +331,17 @@ def oracle_run(case: Case, O, threads: int = 0) -> dict:
     """binds the case on a fresh material and renders it with the CPU oracle"""
     with Material() as mat:
         src, sd = case.bind(mat)
-        uni = O.Uniforms(O.props_from_material(mat), prims=case.prims)
+        shadow_map = None
+        if case.shadow:
+            with Material() as sm_mat:                      # the depth pass sees the same scene through the shadow camera
+                case.bind(sm_mat)
+                extra = case.bind_shadow_pass(sm_mat)
+                su = O.Uniforms(O.props_from_material(sm_mat), prims=case.prims)
+                kind, sw, sh = case.shadow
+                shadow_map = (O.shadowmap_perspective(su, sw, sh, threads=threads) if kind == "persp"
+                              else O.shadowmap_directional(su, extra[0], extra[1], sw, sh, threads=threads))["depth"]
+            case.bind_shadow_lookup(mat)
+        uni = O.Uniforms(O.props_from_material(mat), prims=case.prims, shadow_map=shadow_map)
         if case.kind == "frag":
             return O.render(uni, case.w, case.h, src=src, scene_depth=sd, threads=threads, want_steps=True)
         if case.kind == "shadow_persp":

@@ -38,9 +38,31 @@ def gpu_run(case, torch, host_path=False, kernel=0, frames=1):
     with Material() as mat:
         mat.set_kernel(kernel)
         src, sd = case.bind(mat)
+        if case.shadow:
+            _bind_gpu_shadow_map(case, torch, mat)
         for _ in range(frames - 1):
             _render_once(case, torch, mat, src, sd, host_path)
         return _render_once(case, torch, mat, src, sd, host_path)
+
+
+def _bind_gpu_shadow_map(case, torch, mat):
+    """renders the case's shadow map with the library's own depth pass and binds it as Raymarching.cs:91-93 would"""
+    from raymarching_amd import Material
+    from raymarching_amd.material import _fp, _ptr, current_stream_handle
+    kind, sw, sh = case.shadow
+    depth = torch.zeros((sh, sw), dtype=torch.float32, device="cuda:0")
+    with Material() as sm_mat:
+        case.bind(sm_mat)
+        extra = case.bind_shadow_pass(sm_mat)
+        if kind == "persp":
+            sm_mat._ck(sm_mat._lib.rm_shadowmap_render_device(sm_mat.handle, _ptr(depth), None, sw, sh, current_stream_handle("cuda:0")))
+        else:
+            c, f = np.ascontiguousarray(extra[0]), np.ascontiguousarray(extra[1])
+            sm_mat._ck(sm_mat._lib.rm_shadowmap_directional_device(sm_mat.handle, _fp(c), _fp(f), _ptr(depth), None, sw, sh,
+                                                                   current_stream_handle("cuda:0")))
+        torch.cuda.synchronize()
+    mat.SetTexture("_ShadowMap", depth)
+    case.bind_shadow_lookup(mat)
 
 
 def _render_once(case, torch, mat, src, sd, host_path):
@@ -547,3 +569,35 @@ def test_compact_transport_all_hit_and_no_hit(torch_cuda, w, h):
         mat.expand_frames(records, 0, back)
         torch.cuda.synchronize()
         assert bool((back.view(-1, 4) == torch.tensor([255, 128, 0, 255], dtype=torch.uint8, device=dev)).all())
+
+
+@pytest.mark.parametrize("name", ["shadowmap_lookup_persp_320x180", "shadowmap_lookup_dir_320x180"])
+def test_shadow_map_wiring_of_the_script(oracle, torch_cuda, name):
+    """Raymarching.OnRenderImage with the three lines the reference keeps commented out (Raymarching.cs:91-93) switched on:
+    shadowMap.Render(), SetTexture("_ShadowMap"), SetMatrix("_ShadowMapVPMatrix"), then the blit reads the map"""
+    torch = torch_cuda
+    from raymarching_amd import Material, Raymarching, RenderTexture, ShadowMap, ShadowMapDirectional, scenes
+    case = cases.BY_NAME[name]
+    ref = cases.oracle_run(case, oracle)
+    kind, sw, sh = case.shadow
+    with Material() as mat:
+        mat.SetVector("_WorldSpaceLightPos0", scenes.WORLD_SPACE_LIGHT_POS0)
+        target = RenderTexture(sw, sh, device="cuda:0")
+        sm = (ShadowMap(cases.light_camera(sw, sh), mat, target) if kind == "persp"
+              else ShadowMapDirectional(cases.light_rectangle(), mat, target))
+        rm = Raymarching(scenes.default_camera(case.w, case.h), mat, scenes.default_transforms(), shadowMap=sm)
+        rt = RenderTexture(case.w, case.h, device="cuda:0")
+        for _ in range(2):
+            rm.OnRenderImage(None, rt)
+        st = mat.stats()
+        torch.cuda.synchronize()
+        got = {"rgba": rt.color.cpu().numpy(), "depth": rt.depth.cpu().numpy(), "hit": rt.hit.cpu().numpy()}
+        assert_frame_equal(got, ref, name)
+        assert st["sum_steps_s"] == 0 and st["sum_steps_p"] == ref["stats"]["sum_steps_p"]
+        # unbinding the map with the mode still set is an error, not a crash
+        mat.SetTexture("_ShadowMap", None)
+        from raymarching_amd import native
+        with pytest.raises(native.RmError):
+            rm.bind()
+            from raymarching_amd import Graphics
+            Graphics.Blit(None, rt, mat)
