@@ -287,10 +287,8 @@ RmPrimDev prepare_prim(const rm_primitive &p, int *flags_out) {
     int flags = 0;
     if (p.quat[0] == 0.0f && p.quat[1] == 0.0f && p.quat[2] == 0.0f && p.quat[3] == 1.0f) flags |= RM_PF_IDENT_ROT;
     if (p.scale[0] == 1.0f && p.scale[1] == 1.0f && p.scale[2] == 1.0f) flags |= RM_PF_UNIT_SCALE;
-    if (rcp_safe(p.scale[0]) && rcp_safe(p.scale[1]) && rcp_safe(p.scale[2])) {
-        flags |= RM_PF_RCP;
-        d.rx = 1.0f / p.scale[0]; d.ry = 1.0f / p.scale[1]; d.rz = 1.0f / p.scale[2];
-    }
+    if (rcp_safe(p.scale[0]) && rcp_safe(p.scale[1]) && rcp_safe(p.scale[2])) flags |= RM_PF_RCP;
+    d.rx = 1.0f / p.scale[0]; d.ry = 1.0f / p.scale[1]; d.rz = 1.0f / p.scale[2];      // exact-division use only under RM_PF_RCP
     if (p.op & (RM_OP_SMAX | RM_OP_NEGATE)) flags |= RM_PF_CSG;
     *flags_out = flags;
     d.nsgn = (p.op & RM_OP_NEGATE) ? -1.0f : 1.0f;
@@ -576,7 +574,8 @@ constexpr size_t queue_words(uint32_t bm_cap) { return RM_Q_HDR + 3 * (size_t)RM
 // not fit a workgroup) and the caller did not insist on it
 constexpr int RM_FALLBACK_TILE = 1;
 
-int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, bool streamk, WorkMem &M, bool forced) {
+int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, int family, WorkMem &M, bool forced) {
+    const bool streamk = family == RM_KERNEL_STREAM, fast = family == RM_KERNEL_FAST;
     QueueState &S = *M.q;
     const uint32_t tx = (uint32_t)(P.w + RM_TW - 1) / RM_TW, ty = (uint32_t)(P.rows + RM_TH - 1) / RM_TH;
     const uint64_t n_tiles64 = (uint64_t)tx * ty * (uint64_t)P.n_poses;
@@ -597,11 +596,11 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, bool streamk, WorkM
         return fail(c, RM_E_RANGE, "the persistent kernel's tile bitmap and primitive table do not fit one workgroup's LDS for this frame");
     }
     const int vi = rm_variant_index(P), tab = P.n_prims > 0 ? 1 : 0;
-    const uint64_t occ_key = ((uint64_t)(streamk ? 1 : 0) << 60) | ((uint64_t)vi << 52) | ((uint64_t)tab << 48) | (uint64_t)lds_bytes;
+    const uint64_t occ_key = ((uint64_t)(streamk ? 1 : fast ? 2 : 0) << 60) | ((uint64_t)vi << 52) | ((uint64_t)tab << 48) | (uint64_t)lds_bytes;
     auto occ_it = c->occ.find(occ_key);
     if (occ_it == c->occ.end()) {
         int o[2] = {0, 0};
-        RM_HIP(c, streamk ? rm_launch_stream(P, 0, stream, o) : rm_launch_queue(P, 0, stream, o));
+        RM_HIP(c, streamk ? rm_launch_stream(P, 0, stream, o) : fast ? rm_launch_fast(P, 0, stream, o) : rm_launch_queue(P, 0, stream, o));
         occ_it = c->occ.emplace(occ_key, o[tab] > 0 ? o[tab] : 1).first;
     }
 
@@ -676,7 +675,8 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, bool streamk, WorkM
     {
         // every frame clears the counter set and lists of a later frame: if this launch does not happen,
         // that rotation is broken and the next launch has to start from a zeroed state
-        hipError_t le = streamk ? rm_launch_stream(P, blocks, stream, nullptr) : rm_launch_queue(P, blocks, stream, nullptr);
+        hipError_t le = streamk ? rm_launch_stream(P, blocks, stream, nullptr)
+                      : fast ? rm_launch_fast(P, blocks, stream, nullptr) : rm_launch_queue(P, blocks, stream, nullptr);
         if (le != hipSuccess) {
             S.dirty = true;
             S.history = false;
@@ -740,6 +740,9 @@ int launch(rm_ctx *c, const RmParams &U, hipStream_t stream, WorkMem M, bool rec
     const bool forced = c->kernel != RM_KERNEL_AUTO;
     int kernel = forced ? c->kernel
                : ((U.n_prims > 0 || U.body != RM_BODY_PRIMS || U.mode != RM_MODE_FRAG) ? RM_KERNEL_TILE : RM_KERNEL_QUEUE);
+    // the tolerance kernel exists for the reference's 4-slot scene only; anything else takes the automatic (exact) choice
+    if (kernel == RM_KERNEL_FAST && (U.n_prims > 0 || U.body != RM_BODY_PRIMS))
+        kernel = (U.n_prims > 0 || U.body != RM_BODY_PRIMS || U.mode != RM_MODE_FRAG) ? RM_KERNEL_TILE : RM_KERNEL_QUEUE;
     if (U.body != RM_BODY_PRIMS && kernel == RM_KERNEL_STREAM) kernel = RM_KERNEL_QUEUE;      // no stream kernel for the fractal bodies
     if (U.mode == RM_MODE_FRAG && (U.fx_flags != 0 || U.fx_view != 0)) kernel = RM_KERNEL_TILE;   // the optional frag lines exist in the tile kernels only
     if (U.dom_op != RM_DOM_NONE) kernel = RM_KERNEL_TILE;                                          // and so do the domain operators
@@ -748,7 +751,7 @@ int launch(rm_ctx *c, const RmParams &U, hipStream_t stream, WorkMem M, bool rec
     int rc = order_after_last(c, stream);
     if (rc) return rc;
     if (kernel != RM_KERNEL_TILE) {
-        rc = launch_queue(c, P, stream, kernel == RM_KERNEL_STREAM, M, forced);
+        rc = launch_queue(c, P, stream, kernel, M, forced);
         if (rc == RM_FALLBACK_TILE) kernel = RM_KERNEL_TILE;
         else if (rc) return rc;
     }
@@ -924,7 +927,7 @@ int rm_set_primitives(rm_ctx *c, const rm_primitive *prims, int n) {
 int rm_set_kernel(rm_ctx *c, int variant) {
     RM_TRY
     if (!c) return RM_E_ARG;
-    if (variant != RM_KERNEL_AUTO && variant != RM_KERNEL_TILE && variant != RM_KERNEL_QUEUE && variant != RM_KERNEL_STREAM) return fail(c, RM_E_ARG, "unknown kernel variant");
+    if (variant < RM_KERNEL_AUTO || variant > RM_KERNEL_FAST) return fail(c, RM_E_ARG, "unknown kernel variant");
     c->kernel = variant;
     return RM_OK;
     RM_CATCH(c)

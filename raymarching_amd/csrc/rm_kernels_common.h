@@ -46,11 +46,13 @@ RM_DI MarchResult rm_raymarch(const S &sc, V3 ro, V3 rd, float depth, int n_step
     MarchResult r;
     r.evals = 0;
     float dm = 0.0f, adts = __builtin_inff(), contact = 0.0f;
+    constexpr bool FAST = rm_is_fast<S>::value;
     for (int i = 0; i < n_steps; i++) {
-        V3 cp = mk3(ro.x + rd.x * dm, ro.y + rd.y * dm, ro.z + rd.z * dm);
-        adts = fabsf(sc.w(cp));
+        V3 cp = FAST ? mk3(__builtin_fmaf(rd.x, dm, ro.x), __builtin_fmaf(rd.y, dm, ro.y), __builtin_fmaf(rd.z, dm, ro.z))
+                     : mk3(ro.x + rd.x * dm, ro.y + rd.y * dm, ro.z + rd.z * dm);
+        adts = fabsf(sc.wm(cp));
         r.evals++;
-        dm += adts * sf;
+        dm = FAST ? __builtin_fmaf(adts, sf, dm) : dm + adts * sf;
         contact = dm * kc;
         if (adts < contact) break;
         if (dm > depth) break;
@@ -71,12 +73,15 @@ RM_DI float rm_getshadow(const S &sc, V3 p, V3 n, V3 L, float contact, float dep
     float dm = 0.0f, res = 1.0f;
     p = mk3(p.x + (n.x * contact) * 2.0f, p.y + (n.y * contact) * 2.0f, p.z + (n.z * contact) * 2.0f);
     int ev = 0;
+    constexpr bool FAST = rm_is_fast<S>::value;
     for (int i = 0; i < n_steps; i++) {
-        V3 cp = mk3(p.x + L.x * dm, p.y + L.y * dm, p.z + L.z * dm);
-        float dts = sc.w(cp);
+        V3 cp = FAST ? mk3(__builtin_fmaf(L.x, dm, p.x), __builtin_fmaf(L.y, dm, p.y), __builtin_fmaf(L.z, dm, p.z))
+                     : mk3(p.x + L.x * dm, p.y + L.y * dm, p.z + L.z * dm);
+        float dts = sc.wm(cp);
         ev++;
-        res = fminf(res, 16.0f * dts / dm);
-        dm += fabsf(dts) * sf;
+        // (fast: v_rcp_f32 is within 1 ulp; at dm == 0 it gives inf, and dts * inf is the +-inf / NaN that dts / 0 is)
+        res = fminf(res, FAST ? (16.0f * dts) * __builtin_amdgcn_rcpf(dm) : 16.0f * dts / dm);
+        dm = FAST ? __builtin_fmaf(fabsf(dts), sf, dm) : dm + fabsf(dts) * sf;
         contact = dm * kc;
         if (fabsf(dts) < contact) break;
         if (dm > depth) break;

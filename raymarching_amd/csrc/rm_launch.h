@@ -4,7 +4,7 @@
 #include "rm_device.h"
 
 // kernel variants selectable through rm_set_kernel()
-enum { RM_KERNEL_AUTO = 0, RM_KERNEL_TILE = 1, RM_KERNEL_QUEUE = 2, RM_KERNEL_STREAM = 3 };
+enum { RM_KERNEL_AUTO = 0, RM_KERNEL_TILE = 1, RM_KERNEL_QUEUE = 2, RM_KERNEL_STREAM = 3, RM_KERNEL_FAST = 4 };
 
 // one-thread-per-pixel tile kernel over U.w x U.rows x U.n_poses
 hipError_t rm_launch_tiles(const RmParams &U, hipStream_t stream);
@@ -36,3 +36,7 @@ int rm_variant_index(const RmParams &U);
 
 // persistent kernel with lane-level ray compaction; same calling convention as rm_launch_queue
 hipError_t rm_launch_stream(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu);
+
+// the persistent kernel with the march loops on the fast (tolerance, not bit-exact) distance evaluation; 4-slot scenes
+// only; same calling convention as rm_launch_queue
+hipError_t rm_launch_fast(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu);

@@ -77,6 +77,10 @@ RM_DI V3 rm_lerp3(V3 a, V3 b, float t) { return mk3(rm_lerp(a.x, b.x, t), rm_ler
 RM_DI float rm_clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 RM_DI V3 rm_normalize(V3 a) { float r = 1.0f / sqrtf(rm_dot3(a, a)); return mk3(a.x * r, a.y * r, a.z * r); }   // once per pixel: generic sqrt
 
+// Scene classes whose march loops may round differently from a strict binary32 evaluation (the opt-in tolerance
+// kernel, rm_fast.h) say so here; the loops then fuse their own multiply-adds too.
+template <class S> struct rm_is_fast { static constexpr bool value = false; };
+
 // scale handling chosen per scene on the host
 enum { RM_SCL_UNIT = 0, RM_SCL_RCP = 1, RM_SCL_DIV = 2 };
 
@@ -227,6 +231,7 @@ struct Scene4 {
         float o3 = rm_prim_typed<ROT, SCL>(P3, 3, p, tiny);
         return rm_smin_w(rm_smin_w(o0, o1), rm_smin_w(o2, o3));
     }
+    RM_DI float wm(V3 p) const { return w(p); }      // the evaluation the two march loops use (a kernel may relax it)
     RM_DI V4 full(V3 p) const {
         V4 o[4];
         o[0].w = rm_prim_typed<ROT, SCL>(P0, 0, p, tiny);
@@ -358,6 +363,7 @@ struct SceneN {
         if (csg) return tree<float, true>([&](int i, float &s, int &tw) { return leaf_w<true>(i, p, s, tw); });
         return tree<float, false>([&](int i, float &s, int &tw) { return leaf_w<false>(i, p, s, tw); });
     }
+    RM_DI float wm(V3 p) const { return w(p); }
     RM_DI V4 full(V3 p) const {
         if (csg) return tree<V4, true>([&](int i, float &s, int &tw) { return leaf4<true>(i, p, s, tw); });
         return tree<V4, false>([&](int i, float &s, int &tw) { return leaf4<false>(i, p, s, tw); });
@@ -640,6 +646,7 @@ struct SceneF {
         return o;
     }
     RM_DI float w(V3 p) const { return eval<false>(p).w; }
+    RM_DI float wm(V3 p) const { return w(p); }
     RM_DI V4 full(V3 p) const { return eval<true>(p); }
 };
 
@@ -681,6 +688,7 @@ struct SceneDom {
         return p;
     }
     RM_DI float w(V3 p) const { return in.w(apply(p)); }
+    RM_DI float wm(V3 p) const { return in.wm(apply(p)); }
     RM_DI V4 full(V3 p) const { return in.full(apply(p)); }
 };
 
