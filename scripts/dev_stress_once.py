@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from raymarching_amd import Material, Raymarching, RenderTexture, scenes
 from raymarching_amd.material import _ptr, current_stream_handle
-w, h = 960, 540
+w, h = int(os.environ.get("RM_W", "1920")), int(os.environ.get("RM_H", "1080"))
 with Material() as mat:
     mat.set_kernel(int(os.environ.get("RM_KERNEL", "1")))
     rm = Raymarching(scenes.stress_camera(w, h), mat, scenes.default_transforms()); rm.bind()
