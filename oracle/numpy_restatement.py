@@ -360,6 +360,36 @@ def sierpinski(x, y, z, scale, ms):               # cginc:264-293
     return (o, o2, o3), (np.sqrt(r) - f(2)) * pows[count]
 
 
+def frac(x):
+    return x - np.floor(x)
+
+
+def rand2(x, y):                                  # cginc:125-127
+    return frac(c_sin(x * f(12.9898) + y * f(78.233)) * f(43758.5453))
+
+
+def noise2(x, y):                                 # cginc:129-149
+    ix, iy = np.floor(x), np.floor(y)
+    fx, fy = frac(x), frac(y)
+    a, b = rand2(ix, iy), rand2(ix + f(1), iy + f(0))
+    c, dd = rand2(ix + f(0), iy + f(1)), rand2(ix + f(1), iy + f(1))
+    ux, uy = fx * fx * (f(3) - f(2) * fx), fy * fy * (f(3) - f(2) * fy)
+    return lerp(a, b, ux) + (c - a) * uy * (f(1) - ux) + (dd - b) * ux * uy
+
+
+def terrain_w(x, y):                              # cginc:315-330
+    px, py = x * f(0.003) / f(250), y * f(0.003) / f(250)
+    a, b = np.zeros_like(x), f(1)
+    dx, dy = np.zeros_like(x), np.zeros_like(x)
+    for _ in range(3):
+        n = noise2(px, py)
+        dx, dy = dx + n, dy + f(0)
+        a = a + b * n / (f(1) + (dx * dx + dy * dy))
+        b = b * f(.5)
+        px, py = f(.8) * px * f(2), f(-.6) * py * f(2)
+    return f(250) * f(120) * a
+
+
 class Scene:
     COLORS = ((1, .25, .25), (.25, 1, .25), (.25, .25, 1), (1, 1, .25))     # cginc:356-359
 
@@ -446,6 +476,9 @@ class Scene:
                 c, dist = menger(lx, ly, lz, self.fms)
             elif self.body == 2:
                 c, dist = sierpinski(lx, ly, lz, self.fscale, self.fms)
+            elif self.body == 5:                  # t = terrain(p.xz); float4(t.rgb, p.y - t.w)
+                one = np.ones_like(lx)
+                c, dist = (one, one, one), ly - terrain_w(lx, lz)
             else:
                 c, dist = _bulb(lx, ly, lz, self.fpower, self.body == 4)
             return c, dist * np.fmin(s[0], np.fmin(s[1], s[2]))
@@ -611,7 +644,9 @@ def render(props, w, h, prims=None, src=None, scene_depth=None, shadow_map=None)
 
     # lines the reference keeps commented out in frag, switched on by properties (all off = the shader as is)
     fx_heat, fx_view = props.get("_RmStepHeat", 0) != 0, int(props.get("_RmDebugView", 0))
-    fx_vol, fx_bounce = props.get("_RmVolumetricLight", 0) != 0, props.get("_RmBounce", 0) != 0
+    fx_vol, fx_bounce = props.get("_RmVolumetricLight", 0) != 0, int(props.get("_RmBounce", 0))
+    light_model, fx_scatter = int(props.get("_RmLightModel", 0)), props.get("_RmScatter", 0) != 0
+    lp = np.asarray(props.get("_LightPosition", (0, 0, 0, 0)), dtype=f)
     r_steps = march.last_steps.astype(f)
     r_len, r_hit = length.copy(), hit.copy()          # the ray `r` that frag ends up with (the bounced one, if any)
     rox, roy, roz, rrx, rry, rrz = ox.copy(), oy.copy(), oz.copy(), rdx.copy(), rdy.copy(), rdz.copy()
@@ -649,6 +684,11 @@ def render(props, w, h, prims=None, src=None, scene_depth=None, shadow_map=None)
                 gx = np.where(k < 0, f(0), ix * eta - ux * tt)
                 gy = np.where(k < 0, f(0), iy * eta - uy * tt)
                 gz = np.where(k < 0, f(0), iz * eta - uz * tt)
+                if fx_bounce == 2:                                                              # refract2, shader:142-147
+                    e2 = f(2) - f(props["_RefractiveIndex"])
+                    cosi = dot(ux, uy, uz, ix, iy, iz)
+                    t2 = -cosi + e2 * cosi
+                    gx, gy, gz = ix * e2 - ux * t2, iy * e2 - uy * t2, iz * e2 - uz * t2
                 inside = scene.eval(hx, hy, hz)[1] >= 0
                 nrx, nry, nrz = np.where(inside, gx, fx_), np.where(inside, gy, fy_), np.where(inside, gz, fz_)
             bh, _, bl, _ = march(scene, bx, by, bz, nrx, nry, nrz, np.full(idx.size, sd_full, dtype=f), steps, sf)
@@ -674,6 +714,17 @@ def render(props, w, h, prims=None, src=None, scene_depth=None, shadow_map=None)
         with np.errstate(all="ignore"):
             shadow = (res - f(0)) / (f(1) - f(0)) * (f(1) - f(.25)) + f(.25)                    # cginc:80-82
             ndl = dot(ux, uy, uz, L[0], L[1], L[2]) * f(.5) + f(.5)
+            if light_model:                                                                     # shader:84-100, light of :157-162
+                qx, qy, qz = hx - lp[0], hy - lp[1], hz - lp[2]
+                dist = np.sqrt(dot(qx, qy, qz, qx, qy, qz))
+                dn = dot(ux, uy, uz, lp[0] - hx, lp[1] - hy, lp[2] - hz)
+                if light_model == 2:
+                    br = lerp(clamp(dn, 0, 1) * f(1), f(0), dist / f(1000))
+                else:
+                    dd = clamp(dn, -1, 1) * f(.5) + f(.5)
+                    dd = dd * dd
+                    br = lerp(dd * f(1), f(0), dist / f(1000))
+                ndl = np.where(dist >= f(1000), f(0), br)
             nss = f(props["_NormalSampleScale"])
             ao = clamp(length3(nx / nss, ny / nss, nz / nss), 0, 1)                             # shader:125-127
             shaded = [((srgb[j] * ndl) * shadow) * ao for j in range(3)]                        # shader:199
@@ -691,6 +742,14 @@ def render(props, w, h, prims=None, src=None, scene_depth=None, shadow_map=None)
         if fx_heat:                                                                             # shader:203
             hterm = r_steps / f(100) * sf
             col = [c + hterm for c in col]
+        if fx_scatter:                                                                          # shader:129-140
+            qx, qy, qz = rox - lp[0], roy - lp[1], roz - lp[2]
+            bb = dot(rrx, rry, rrz, qx, qy, qz)
+            cc = dot(qx, qy, qz, qx, qy, qz)
+            ss = f(1) / np.sqrt(cc - bb * bb)
+            one = np.ones_like(ss)
+            sct = ss * (c_atan2((r_len + bb) * ss, one) - c_atan2(bb * ss, one))
+            col = [c + sct for c in col]
         if fx_vol:                                                                              # shader:206-212
             la = np.zeros(n, dtype=f)
             lim = np.fmin(f(5), r_len)

@@ -380,6 +380,63 @@ static inline f4 sierpinski(f3 p, float scale, const euler_t *rot, const float p
     return out;
 }
 
+/* ---- cginc:125-127  rand: frac(sin(dot(co, float2(12.9898,78.233))) * 43758.5453), with sin the canonical c_sin and
+ * frac(x) = x - floor(x) ------------------------------------------------------------------------------------- */
+static inline float frac1(float x) { return x - floorf(x); }
+static inline float rand2(float x, float y) {
+    return frac1(c_sin(x * 12.9898f + y * 78.233f) * 43758.5453f);
+}
+/* ---- cginc:129-149  noise: value noise, cubic Hermite interpolation of the four corner values ---------------- */
+static inline float noise2(float x, float y) {
+    float ix = floorf(x), iy = floorf(y);
+    float fx = frac1(x), fy = frac1(y);
+    float a = rand2(ix, iy), b = rand2(ix + 1.0f, iy + 0.0f), c = rand2(ix + 0.0f, iy + 1.0f), d = rand2(ix + 1.0f, iy + 1.0f);
+    float ux = fx * fx * (3.0f - 2.0f * fx), uy = fy * fy * (3.0f - 2.0f * fy);
+    return lerp1(a, b, ux) + (c - a) * uy * (1.0f - ux) + (d - b) * ux * uy;
+}
+/* ---- cginc:315-330  terrain(float2 x).w.  `float2 n = noise(p)` broadcasts the scalar; d accumulates in .x only ---- */
+static inline float terrain_w(float x, float y) {
+    float px = x * 0.003f / 250.0f, py = y * 0.003f / 250.0f;
+    float a = 0.0f, b = 1.0f, dx = 0.0f, dy = 0.0f;
+    for (int i = 0; i < 3; i++) {
+        float n = noise2(px, py);
+        dx += n; dy += 0.0f;
+        a += b * n / (1.0f + (dx * dx + dy * dy));
+        b *= 0.5f;
+        px = .8f * px * 2.0f; py = -.6f * py * 2.0f;
+    }
+    return 250.0f * 120.0f * a;
+}
+
+/* atan(x) of getscatter (shader:139) as the canonical atan2(x, 1) */
+static inline float c_atan(float x) { return c_atan2(x, 1.0f); }
+
+/* ---- shader:84-100  getbrightnesshard / getbrightness with the light of shader:157-162 (range 1000, intensity 1) ---- */
+static inline float getbrightness(f3 p, f3 n, f3 lpos, int hard) {
+    const float range = 1000.0f, intensity = 1.0f;
+    float dist = len3(sub3(p, lpos));
+    if (dist >= range) return 0.0f;
+    float dn = dot3(n, sub3(lpos, p));
+    if (hard) return lerp1(clamp1(dn, 0.0f, 1.0f) * intensity, 0.0f, dist / range);
+    float d = clamp1(dn, -1.0f, 1.0f) * .5f + .5f;
+    d *= d;
+    return lerp1(d * intensity, 0.0f, dist / range);
+}
+/* ---- shader:129-140  getscatter(ray r, light l) --------------------------------------------------------------- */
+static inline float getscatter(f3 ro, f3 rd, float length, f3 lpos) {
+    const float intensity = 1.0f;
+    f3 q = sub3(ro, lpos);
+    float b = dot3(rd, q), c = dot3(q, q);
+    float s = intensity / sqrtf(c - b * b);
+    return s * (c_atan((length + b) * s) - c_atan(b * s));
+}
+/* ---- shader:142-147  refract2 ---------------------------------------------------------------------------------- */
+static inline f3 refract2(f3 i, f3 n, float eta) {
+    eta = 2.0f - eta;
+    float cosi = dot3(n, i);
+    return sub3(scl3(i, eta), scl3(n, -cosi + eta * cosi));
+}
+
 /* the reference's fixed scene as a primitive table: sphere, box, link(5,5,.1),
  * cylinder with colours (1,.25,.25) (.25,1,.25) (.25,.25,1) (1,1,.25)
  * (cginc:351-359); positions/rotations/scales from the three matrices */
@@ -424,6 +481,7 @@ static inline f4 scene_fractal(const scene_ctx *c, f3 p) {
     case RMO_BODY_MENGER:     o = menger(pl, &c->frot, c->pow3); break;
     case RMO_BODY_SIERPINSKI: o = sierpinski(pl, c->u->fractal_scale, &c->frot, c->pows); break;
     case RMO_BODY_MANDELBULB: o = mandelbulb(pl, c->fpower); break;
+    case RMO_BODY_TERRAIN:    { f4 t = {1.0f, 1.0f, 1.0f, pl.y - terrain_w(pl.x, pl.z)}; o = t; } break;
     default:                  o = mandelbrot3(pl, c->fpower); break;
     }
     o.w = o.w * min3(s);
@@ -714,14 +772,15 @@ static void frag_pixel(job_t *j, int x, int y, rmo_stats *st) {
     f3 col = tex;
     int sev = 0;
     const march_t primary = r;                                        /* depth / mask outputs describe the camera ray */
-    const int fx = u->fx_step_heat || u->fx_debug_view || u->fx_volumetric || u->fx_bounce;
+    const int fx = u->fx_step_heat || u->fx_debug_view || u->fx_volumetric || u->fx_bounce || u->fx_scatter;
     if (r.hit || u->shade_miss_pixels || fx) {
         f3 hitpoint = add3(ro, scl3(rd, r.length));                   /* shader:174 */
         f3 rawnormal = getnormalraw(c, hitpoint);
         f3 normal = normalize3(rawnormal);
         if (u->fx_bounce && r.hit) {                                  /* shader:178-187, one round */
             ro = sub3(hitpoint, scl3(scl3(normal, r.contact), 2.0f));
-            rd = scene_w(c, hitpoint) >= 0.0f ? hlsl_refract(rd, normal, 1.1f) : hlsl_reflect(rd, normal);
+            rd = scene_w(c, hitpoint) >= 0.0f ? (u->fx_bounce == 2 ? refract2(rd, normal, u->refractive_index) : hlsl_refract(rd, normal, 1.1f))
+                                              : hlsl_reflect(rd, normal);
             r = raymarch(c, ro, rd, 2000.0f, r.contact);
             hitpoint = add3(ro, scl3(rd, r.length));
             rawnormal = getnormalraw(c, hitpoint);
@@ -732,6 +791,8 @@ static void frag_pixel(job_t *j, int x, int y, rmo_stats *st) {
         float sh = u->shadow_mode != 0 ? shadow_lookup(c, hitpoint, normal, r.contact) : getshadow(c, hitpoint, normal, r.contact, &sev);
         float shadow = remap(sh, 0.0f, 1.0f, .25f, 1.0f);
         float ndl = dot3(normal, c->light) * .5f + .5f;
+        if (u->fx_light_model)
+            ndl = getbrightness(hitpoint, normal, v3(u->light_position[0], u->light_position[1], u->light_position[2]), u->fx_light_model == 2);
         f3 shaded = scl3(scl3(scl3(srgb, ndl), shadow), getAO(c, rawnormal));
         if (u->fx_debug_view == 1) shaded = v3(shadow, shadow, shadow);                                    /* shader:200 */
         if (u->fx_debug_view == 2) shaded = v3(normal.x * .5f + .5f, normal.y * .5f + .5f, normal.z * .5f + .5f);   /* :201 */
@@ -743,6 +804,10 @@ static void frag_pixel(job_t *j, int x, int y, rmo_stats *st) {
     if (u->fx_step_heat) {                                            /* shader:203 */
         float h = (float)r.steps / 100.0f * u->step_factor;
         col = v3(col.x + h, col.y + h, col.z + h);
+    }
+    if (u->fx_scatter) {                                              /* shader:129-140, added like the light integration below */
+        float sc = getscatter(ro, rd, r.length, v3(u->light_position[0], u->light_position[1], u->light_position[2]));
+        col = v3(col.x + sc, col.y + sc, col.z + sc);
     }
     if (u->fx_volumetric) {                                           /* shader:206-212 */
         float la = 0.0f;
@@ -910,6 +975,20 @@ float rmo_c_asin(float x) { return c_asin(x); }
 float rmo_c_atan2(float y, float x) { return c_atan2(y, x); }
 float rmo_c_log(float x) { return c_log(x); }
 float rmo_c_pow(float x, float e) { return c_pow(x, e); }
+float rmo_c_atan(float x) { return c_atan(x); }
+float rmo_rand(const float co[2]) { return rand2(co[0], co[1]); }
+float rmo_noise(const float st[2]) { return noise2(st[0], st[1]); }
+float rmo_terrain(const float x[2]) { return terrain_w(x[0], x[1]); }
+float rmo_getbrightness(const float p[3], const float n[3], const float lp[3], int hard) {
+    return getbrightness(v3(p[0], p[1], p[2]), v3(n[0], n[1], n[2]), v3(lp[0], lp[1], lp[2]), hard);
+}
+float rmo_getscatter(const float ro[3], const float rd[3], float length, const float lp[3]) {
+    return getscatter(v3(ro[0], ro[1], ro[2]), v3(rd[0], rd[1], rd[2]), length, v3(lp[0], lp[1], lp[2]));
+}
+void rmo_refract2(const float i[3], const float n[3], float eta, float out[3]) {
+    f3 r = refract2(v3(i[0], i[1], i[2]), v3(n[0], n[1], n[2]), eta);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
 void rmo_mandelbulb(const float p[3], float e, float out[4]) {
     f4 r = mandelbulb(v3(p[0], p[1], p[2]), e);
     out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;

@@ -78,7 +78,15 @@ typedef struct {
     int32_t fx_step_heat;        /* col += r.steps / 100 * _StepFactor          (shader:203) */
     int32_t fx_debug_view;       /* 1 shadow (shader:200), 2 normal*.5+.5 (:201), 3 clamp(scene(hitpoint).r*2.5-1.75,0,1) (:198) */
     int32_t fx_volumetric;       /* light integration along the ray              (shader:206-212) */
-    int32_t fx_bounce;           /* one refract/reflect round                    (shader:178-187) */
+    int32_t fx_bounce;           /* one refract/reflect round (shader:178-187); 2: the refracting branch calls the reference's
+                                    own refract2(rd, normal, _RefractiveIndex) (shader:142-147) instead of refract(rd, normal, 1.1) */
+    /* helpers the reference defines and calls from nowhere, wired in as this build defines (0 = the shader as it stands):
+     * the `light l` frag builds at shader:157-162 = {range 1000, intensity 1, position _LightPosition, color (.8,.7,.6)} */
+    int32_t fx_light_model;      /* 1: getbrightness(hitpoint, normal, l) (shader:92-100), 2: getbrightnesshard (shader:84-90)
+                                    takes the place of dot(normal, _WorldSpaceLightPos0)*.5+.5 in the shade (shader:199) */
+    int32_t fx_scatter;          /* col += getscatter(r, l) (shader:129-140) after the shade, like the light integration */
+    float light_position[3];     /* _LightPosition (shader:4,31) */
+    float refractive_index;      /* _RefractiveIndex (shader:11,36) */
     /* domain operators the reference defines but never calls, applied to p at the top of scene():
      * 1 repetition p = shmod(p, period) on the axes whose period is > 0 (cginc:84-99),
      * 2 boxfold(p, size) (cginc:156-159), 3 spherefold(p, size) (cginc:161-165); 0 = none */
@@ -110,7 +118,10 @@ typedef struct {
  * the functions the reference defines but only calls from a commented-out line (cginc:349); here
  * they get the wrapper every primitive gets, with slot 0 of the three matrices:
  *   p0 = rotate(p - _Positions[0], _Rotations[0]);  o = body(p0 / _Scales[0]);  o.w *= min(_Scales[0]) */
-enum { RMO_BODY_PRIMS = 0, RMO_BODY_MENGER = 1, RMO_BODY_SIERPINSKI = 2, RMO_BODY_MANDELBULB = 3, RMO_BODY_MANDELBROT = 4 };
+enum { RMO_BODY_PRIMS = 0, RMO_BODY_MENGER = 1, RMO_BODY_SIERPINSKI = 2, RMO_BODY_MANDELBULB = 3, RMO_BODY_MANDELBROT = 4,
+       /* terrain(float2) (cginc:315-330) returns a height that no code of the reference turns into a distance; this
+        * build's definition of the body: t = terrain(p.xz); float4(t.rgb, p.y - t.w) */
+       RMO_BODY_TERRAIN = 5 };
 
 typedef struct {
     uint64_t n_pixels;
@@ -158,6 +169,13 @@ float rmo_c_asin(float x);
 float rmo_c_atan2(float y, float x);
 float rmo_c_log(float x);
 float rmo_c_pow(float x, float e);
+float rmo_c_atan(float x);
+float rmo_rand(const float co[2]);
+float rmo_noise(const float st[2]);
+float rmo_terrain(const float x[2]);
+float rmo_getbrightness(const float p[3], const float n[3], const float light_pos[3], int hard);
+float rmo_getscatter(const float ro[3], const float rd[3], float length, const float light_pos[3]);
+void  rmo_refract2(const float i[3], const float n[3], float eta, float out[3]);
 void  rmo_mandelbulb(const float p[3], float e, float out[4]);
 void  rmo_mandelbrot(const float p[3], float e, float out[4]);
 void  rmo_menger(const rmo_uniforms *u, const float p[3], float out[4]);

@@ -32,6 +32,8 @@ class RmoUniforms(C.Structure):
                 ("scene_body", C.c_int32), ("fractal_scale", C.c_float), ("fractal_rotation", C.c_float * 3),
                 ("fractal_power", C.c_float), ("fx_step_heat", C.c_int32), ("fx_debug_view", C.c_int32),
                 ("fx_volumetric", C.c_int32), ("fx_bounce", C.c_int32),
+                ("fx_light_model", C.c_int32), ("fx_scatter", C.c_int32), ("light_position", C.c_float * 3),
+                ("refractive_index", C.c_float),
                 ("domain_op", C.c_int32), ("domain_period", C.c_float * 3), ("domain_size", C.c_float),
                 ("shadow_mode", C.c_int32), ("shadow_map", C.POINTER(C.c_float)), ("shadow_w", C.c_int32), ("shadow_h", C.c_int32),
                 ("shadow_vp", C.c_float * 16), ("shadow_corners", C.c_float * 12), ("shadow_forward", C.c_float * 3),
@@ -93,6 +95,17 @@ def lib() -> C.CDLL:
         for fn in (l.rmo_c_sin, l.rmo_c_cos, l.rmo_c_acos, l.rmo_c_asin, l.rmo_c_log):
             fn.restype = C.c_float
             fn.argtypes = [C.c_float]
+        l.rmo_c_atan.restype = C.c_float
+        l.rmo_c_atan.argtypes = [C.c_float]
+        for fn in (l.rmo_rand, l.rmo_noise, l.rmo_terrain):
+            fn.restype = C.c_float
+            fn.argtypes = [FP]
+        l.rmo_getbrightness.restype = C.c_float
+        l.rmo_getbrightness.argtypes = [FP, FP, FP, C.c_int]
+        l.rmo_getscatter.restype = C.c_float
+        l.rmo_getscatter.argtypes = [FP, FP, C.c_float, FP]
+        l.rmo_refract2.restype = None
+        l.rmo_refract2.argtypes = [FP, FP, C.c_float, FP]
         for fn in (l.rmo_c_atan2, l.rmo_c_pow):
             fn.restype = C.c_float
             fn.argtypes = [C.c_float, C.c_float]
@@ -171,7 +184,11 @@ class Uniforms:
         u.fx_step_heat = int(props.get("_RmStepHeat", 0) != 0)
         u.fx_debug_view = int(props.get("_RmDebugView", 0))
         u.fx_volumetric = int(props.get("_RmVolumetricLight", 0) != 0)
-        u.fx_bounce = int(props.get("_RmBounce", 0) != 0)
+        u.fx_bounce = int(props.get("_RmBounce", 0))
+        u.fx_light_model = int(props.get("_RmLightModel", 0))
+        u.fx_scatter = int(props.get("_RmScatter", 0) != 0)
+        u.light_position[:] = f32(props.get("_LightPosition", np.zeros(4)))[:3].tolist()
+        u.refractive_index = props.get("_RefractiveIndex", 1.0)
         u.domain_op = int(props.get("_RmDomainOp", 0))
         u.domain_period[:] = [float(x) for x in list(props.get("_RmDomainPeriod", (0.0, 0.0, 0.0, 0.0)))[:3]]
         u.domain_size = props.get("_RmDomainSize", 1.0)
@@ -198,10 +215,10 @@ class Uniforms:
 
 PROP_MATRICES = ("_FrustrumCorners", "_CameraInvViewMatrix", "_Positions", "_Rotations", "_Scales", "_ShadowMapVPMatrix",
                  "_RmShadowMapCorners")
-PROP_VECTORS = ("_WorldSpaceCameraPos", "_WorldSpaceLightPos0", "_ProjectionParams", "_BackgroundColor", "_RmDomainPeriod", "_RmShadowMapForward")
+PROP_VECTORS = ("_WorldSpaceCameraPos", "_WorldSpaceLightPos0", "_ProjectionParams", "_BackgroundColor", "_RmDomainPeriod", "_RmShadowMapForward", "_LightPosition")
 PROP_FLOATS = ("_MaxSteps", "_MaxDist", "_StepFactor", "_ContactThreshold", "_NormalSampleScale",
                "_FractalScale", "_FractalRotationX", "_FractalRotationY", "_FractalRotationZ", "_RmSceneBody", "_RmFractalPower",
-               "_RmStepHeat", "_RmDebugView", "_RmVolumetricLight", "_RmBounce", "_RmDomainOp", "_RmDomainSize", "_RmShadowMode", "_RmShadowBias")
+               "_RmStepHeat", "_RmDebugView", "_RmVolumetricLight", "_RmBounce", "_RmDomainOp", "_RmDomainSize", "_RmShadowMode", "_RmShadowBias", "_RmLightModel", "_RmScatter", "_RefractiveIndex")
 
 
 def props_from_material(mat) -> dict:

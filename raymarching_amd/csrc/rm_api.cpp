@@ -48,6 +48,9 @@ const char *const kDeclared[] = {
     // lines of frag that the reference keeps commented out: col += r.steps/100*_StepFactor (shader:203), the
     // alternative outputs (:198-201), the light integration along the ray (:206-212), the bounce loop (:178-187)
     "_RmStepHeat", "_RmDebugView", "_RmVolumetricLight", "_RmBounce",
+    // helpers the reference defines and never calls: getbrightness / getbrightnesshard (shader:84-100) in the shade,
+    // getscatter (shader:129-140) added to the colour; _RmBounce 2 refracts with refract2 (shader:142-147)
+    "_RmLightModel", "_RmScatter",
     // shadow-map lookup in place of the shadow march: what reads _ShadowMap / _ShadowMapVPMatrix (shader:45-46)
     "_RmShadowMode", "_RmShadowBias", "_RmShadowMapCorners", "_RmShadowMapForward",
 };
@@ -201,6 +204,8 @@ void load_defaults(rm_ctx *c) {
     c->floats["_RmDebugView"] = 0.0f;
     c->floats["_RmVolumetricLight"] = 0.0f;
     c->floats["_RmBounce"] = 0.0f;
+    c->floats["_RmLightModel"] = 0.0f;
+    c->floats["_RmScatter"] = 0.0f;
     c->floats["_RmShadowMode"] = 0.0f;
     c->floats["_RmShadowBias"] = 0.01f;
     c->matrices["_ShadowMapVPMatrix"] = mat_identity();
@@ -471,8 +476,8 @@ int build_params(rm_ctx *c, RmParams *U, hipStream_t stream) {
     }
     const int body = (int)getf(c, "_RmSceneBody", 0.0f);
     if (body != RM_BODY_PRIMS) {
-        if (body < RM_BODY_MENGER || body > RM_BODY_MANDELBROT)
-            return fail(c, RM_E_ARG, "_RmSceneBody must be 0 (primitives), 1 (menger), 2 (sierpinski), 3 (mandelbulb) or 4 (mandelbrot)");
+        if (body < RM_BODY_MENGER || body > RM_BODY_TERRAIN)
+            return fail(c, RM_E_ARG, "_RmSceneBody must be 0 (primitives), 1 (menger), 2 (sierpinski), 3 (mandelbulb), 4 (mandelbrot) or 5 (terrain)");
         // the wrapper transform is slot 0 of the matrices, whatever table is set
         rm_primitive lp[4];
         legacy_prims(c, lp);
@@ -498,7 +503,16 @@ int build_params(rm_ctx *c, RmParams *U, hipStream_t stream) {
     U->scene_flags = flags;
     U->fx_flags = (getf(c, "_RmStepHeat", 0.0f) != 0.0f ? RM_FX_STEP_HEAT : 0u) |
                   (getf(c, "_RmVolumetricLight", 0.0f) != 0.0f ? RM_FX_VOLUMETRIC : 0u) |
-                  (getf(c, "_RmBounce", 0.0f) != 0.0f ? RM_FX_BOUNCE : 0u);
+                  (getf(c, "_RmBounce", 0.0f) != 0.0f ? RM_FX_BOUNCE : 0u) |
+                  ((int)getf(c, "_RmBounce", 0.0f) == 2 ? RM_FX_REFRACT2 : 0u) |
+                  (getf(c, "_RmScatter", 0.0f) != 0.0f ? RM_FX_SCATTER : 0u);
+    U->light_model = (int32_t)getf(c, "_RmLightModel", 0.0f);
+    if (U->light_model < 0 || U->light_model > 2) return fail(c, RM_E_ARG, "_RmLightModel must be 0, 1 (getbrightness) or 2 (getbrightnesshard)");
+    {
+        const vec4 lp = getv(c, "_LightPosition");
+        U->light_pos[0] = lp[0]; U->light_pos[1] = lp[1]; U->light_pos[2] = lp[2];
+    }
+    U->refr_index = getf(c, "_RefractiveIndex", 1.0f);
     U->fx_view = (int32_t)getf(c, "_RmDebugView", 0.0f);
     if (U->fx_view < 0 || U->fx_view > 3) return fail(c, RM_E_ARG, "_RmDebugView must be 0..3");
     U->shadow_mode = (int32_t)getf(c, "_RmShadowMode", 0.0f);
@@ -744,7 +758,7 @@ int launch(rm_ctx *c, const RmParams &U, hipStream_t stream, WorkMem M, bool rec
     if (kernel == RM_KERNEL_FAST && (U.n_prims > 0 || U.body != RM_BODY_PRIMS))
         kernel = (U.n_prims > 0 || U.body != RM_BODY_PRIMS || U.mode != RM_MODE_FRAG) ? RM_KERNEL_TILE : RM_KERNEL_QUEUE;
     if (U.body != RM_BODY_PRIMS && kernel == RM_KERNEL_STREAM) kernel = RM_KERNEL_QUEUE;      // no stream kernel for the fractal bodies
-    if (U.mode == RM_MODE_FRAG && (U.fx_flags != 0 || U.fx_view != 0)) kernel = RM_KERNEL_TILE;   // the optional frag lines exist in the tile kernels only
+    if (U.mode == RM_MODE_FRAG && (U.fx_flags != 0 || U.fx_view != 0 || U.light_model != 0)) kernel = RM_KERNEL_TILE;   // the optional frag lines exist in the tile kernels only
     if (U.dom_op != RM_DOM_NONE) kernel = RM_KERNEL_TILE;                                          // and so do the domain operators
     if (U.mode == RM_MODE_FRAG && U.shadow_mode != 0) kernel = RM_KERNEL_TILE;                     // and the shadow-map lookup
     if (U.dst_steps) kernel = RM_KERNEL_TILE;                                                      // and the per-pixel step-count plane

@@ -140,6 +140,9 @@ struct RmParams {
     float    f_power;          // e of mandelbulb (cginc:194) / mandelbrot (cginc:229)
     // lines of frag the reference keeps commented out (0 = the shader as it stands); tile kernels only
     uint32_t fx_flags;         // RM_FX_*
+    int32_t  light_model;      // 0 dot(normal, _WorldSpaceLightPos0)*.5+.5 (shader:199), 1 getbrightness (shader:92-100), 2 getbrightnesshard (:84-90)
+    float    light_pos[3];     // _LightPosition: position of the `light l` frag builds (shader:157-162)
+    float    refr_index;       // _RefractiveIndex, the eta of refract2 (shader:142-147)
     int32_t  fx_view;          // 1 shadow (shader:200), 2 normal*.5+.5 (:201), 3 clamp(scene(hitpoint).r*2.5-1.75,0,1) (:198)
     // domain operator applied to p at the top of scene() (functions the reference defines and never calls);
     // tile kernels with the optional lines only
@@ -159,6 +162,6 @@ struct RmParams {
 
 enum : int32_t { RM_DOM_NONE = 0, RM_DOM_REPEAT = 1, RM_DOM_BOXFOLD = 2, RM_DOM_SPHEREFOLD = 3 };
 
-enum : uint32_t { RM_FX_STEP_HEAT = 1, RM_FX_VOLUMETRIC = 2, RM_FX_BOUNCE = 4 };
+enum : uint32_t { RM_FX_STEP_HEAT = 1, RM_FX_VOLUMETRIC = 2, RM_FX_BOUNCE = 4, RM_FX_SCATTER = 8, RM_FX_REFRACT2 = 16 };
 
-enum : int32_t { RM_BODY_PRIMS = 0, RM_BODY_MENGER = 1, RM_BODY_SIERPINSKI = 2, RM_BODY_MANDELBULB = 3, RM_BODY_MANDELBROT = 4 };
+enum : int32_t { RM_BODY_PRIMS = 0, RM_BODY_MENGER = 1, RM_BODY_SIERPINSKI = 2, RM_BODY_MANDELBULB = 3, RM_BODY_MANDELBROT = 4, RM_BODY_TERRAIN = 5 };

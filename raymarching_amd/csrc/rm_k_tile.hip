@@ -229,7 +229,7 @@ hipError_t rm_launch_tiles(const RmParams &U, hipStream_t stream) {
     if (U.w <= 0 || U.rows <= 0 || U.n_poses <= 0) return hipErrorInvalidValue;
     dim3 grid((unsigned)((U.w + 8 * RM_BWX - 1) / (8 * RM_BWX)), (unsigned)((U.rows + 8 * RM_BWY - 1) / (8 * RM_BWY)), (unsigned)U.n_poses);
     if (grid.y > 65535u || grid.z > 65535u) return hipErrorInvalidValue;
-    if (U.fx_flags != 0 || U.fx_view != 0 || U.dom_op != RM_DOM_NONE || (U.mode == RM_MODE_FRAG && U.shadow_mode != 0)) return rm_launch_tiles_fx(U, grid.x, grid.y, grid.z, stream);
+    if (U.fx_flags != 0 || U.fx_view != 0 || U.light_model != 0 || U.dom_op != RM_DOM_NONE || (U.mode == RM_MODE_FRAG && U.shadow_mode != 0)) return rm_launch_tiles_fx(U, grid.x, grid.y, grid.z, stream);
     if (U.body != RM_BODY_PRIMS) {
         hipLaunchKernelGGL(rm_tile_kernelF, grid, dim3(RM_BLOCK), 0, stream, U);
         return hipGetLastError();

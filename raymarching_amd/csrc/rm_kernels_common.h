@@ -224,6 +224,32 @@ RM_DI V3 rm_refract(V3 i, V3 n, float eta) {
     return mk3(i.x * eta - n.x * t, i.y * eta - n.y * t, i.z * eta - n.z * t);
 }
 
+// shader:142-147
+RM_DI V3 rm_refract2(V3 i, V3 n, float eta) {
+    eta = 2.0f - eta;
+    const float cosi = rm_dot3(n, i);
+    const float t = -cosi + eta * cosi;
+    return mk3(i.x * eta - n.x * t, i.y * eta - n.y * t, i.z * eta - n.z * t);
+}
+// shader:84-100 with the light of shader:157-162 (range 1000, intensity 1)
+RM_DI float rm_getbrightness(V3 p, V3 n, V3 lp, bool hard) {
+    const float range = 1000.0f, intensity = 1.0f;
+    const float dist = sqrtf(rm_dot3(mk3(p.x - lp.x, p.y - lp.y, p.z - lp.z), mk3(p.x - lp.x, p.y - lp.y, p.z - lp.z)));
+    if (dist >= range) return 0.0f;
+    const float dn = rm_dot3(n, mk3(lp.x - p.x, lp.y - p.y, lp.z - p.z));
+    if (hard) return rm_lerp(rm_clamp01(dn) * intensity, 0.0f, dist / range);
+    float d = fminf(fmaxf(dn, -1.0f), 1.0f) * .5f + .5f;
+    d *= d;
+    return rm_lerp(d * intensity, 0.0f, dist / range);
+}
+// shader:129-140; atan(x) = the canonical atan2(x, 1)
+RM_DI float rm_getscatter(V3 ro, V3 rd, float length, V3 lp) {
+    const V3 q = mk3(ro.x - lp.x, ro.y - lp.y, ro.z - lp.z);
+    const float b = rm_dot3(rd, q), c = rm_dot3(q, q);
+    const float s = 1.0f / sqrtf(c - b * b);
+    return s * (rm_c_atan2((length + b) * s, 1.0f) - rm_c_atan2(b * s, 1.0f));
+}
+
 template <class S>
 RM_DI V3 rm_normal_raw(const RmParams &U, const S &sc, V3 hp) {
     const float e = U.nss;
@@ -297,7 +323,7 @@ RM_DI PixelOut rm_compute_pixel_fx(const RmParams &U, const S &sc, int x, int yl
         V3 n = rm_normalize(raw);
         if (U.fx_flags & RM_FX_BOUNCE) {
             ro = mk3(hp.x - (n.x * r.contact) * 2.0f, hp.y - (n.y * r.contact) * 2.0f, hp.z - (n.z * r.contact) * 2.0f);
-            rd = sc.w(hp) >= 0.0f ? rm_refract(rd, n, 1.1f) : rm_reflect(rd, n);
+            rd = sc.w(hp) >= 0.0f ? ((U.fx_flags & RM_FX_REFRACT2) ? rm_refract2(rd, n, U.refr_index) : rm_refract(rd, n, 1.1f)) : rm_reflect(rd, n);
             r = rm_raymarch(sc, ro, rd, fminf(2000.0f, U.max_dist), U.n_steps, sf);
             hp = mk3(ro.x + rd.x * r.length, ro.y + rd.y * r.length, ro.z + rd.z * r.length);
             raw = rm_normal_raw(U, sc, hp);
@@ -312,6 +338,7 @@ RM_DI PixelOut rm_compute_pixel_fx(const RmParams &U, const S &sc, int x, int yl
         if (r.hit) {                                           // the bounced ray may have missed: then tex stays
             float shadow = sh * 0.75f + .25f;
             float ndl = rm_dot3(n, L) * .5f + .5f;
+            if (U.light_model != 0) ndl = rm_getbrightness(hp, n, mk3(U.light_pos[0], U.light_pos[1], U.light_pos[2]), U.light_model == 2);
             float ao = rm_clamp01(rm_len3(mk3(raw.x / U.nss_raw, raw.y / U.nss_raw, raw.z / U.nss_raw)));
             col = mk3(((s.x * ndl) * shadow) * ao, ((s.y * ndl) * shadow) * ao, ((s.z * ndl) * shadow) * ao);
             if (U.fx_view == 1) col = mk3(shadow, shadow, shadow);
@@ -322,6 +349,10 @@ RM_DI PixelOut rm_compute_pixel_fx(const RmParams &U, const S &sc, int x, int yl
     if (U.fx_flags & RM_FX_STEP_HEAT) {
         const float h = (float)r.steps / 100.0f * U.step_factor;
         col = mk3(col.x + h, col.y + h, col.z + h);
+    }
+    if (U.fx_flags & RM_FX_SCATTER) {
+        const float sct = rm_getscatter(ro, rd, r.length, mk3(U.light_pos[0], U.light_pos[1], U.light_pos[2]));
+        col = mk3(col.x + sct, col.y + sct, col.z + sct);
     }
     if (U.fx_flags & RM_FX_VOLUMETRIC) {
         float la = 0.0f;

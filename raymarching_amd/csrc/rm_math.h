@@ -633,6 +633,37 @@ struct SceneF {
         if (TRAPS) { o.x = rm_sqrt(t0); o.y = rm_sqrt(t1); o.z = rm_sqrt(t2); } else { o.x = o.y = o.z = 0.0f; }
         return o;
     }
+    // cginc:125-149: rand / noise with the canonical sin (double series) and frac(x) = x - floor(x)
+    RM_DI static float rand2(float x, float y) {
+        float sn, cs;
+        rm_c_sincos(x * 12.9898f + y * 78.233f, sn, cs);
+        const float v = sn * 43758.5453f;
+        return v - floorf(v);
+    }
+    RM_DI static float noise2(float x, float y) {
+        const float ix = floorf(x), iy = floorf(y);
+        const float fx = x - ix, fy = y - iy;
+        const float a = rand2(ix, iy), b = rand2(ix + 1.0f, iy + 0.0f), c = rand2(ix + 0.0f, iy + 1.0f), d = rand2(ix + 1.0f, iy + 1.0f);
+        const float ux = fx * fx * (3.0f - 2.0f * fx), uy = fy * fy * (3.0f - 2.0f * fy);
+        return rm_lerp(a, b, ux) + (c - a) * uy * (1.0f - ux) + (d - b) * ux * uy;
+    }
+    // cginc:315-330 as a body: t = terrain(p.xz); float4(t.rgb, p.y - t.w)
+    RM_DI V4 terrain(V3 p) const {
+        float px = p.x * 0.003f / 250.0f, py = p.z * 0.003f / 250.0f;
+        float a = 0.0f, b = 1.0f, dx = 0.0f, dy = 0.0f;
+#pragma nounroll
+        for (int i = 0; i < 3; i++) {
+            const float n = noise2(px, py);
+            dx += n; dy += 0.0f;
+            a += b * n / (1.0f + (dx * dx + dy * dy));
+            b *= 0.5f;
+            px = .8f * px * 2.0f; py = -.6f * py * 2.0f;
+        }
+        V4 o;
+        o.x = o.y = o.z = 1.0f;
+        o.w = p.y - 250.0f * 120.0f * a;
+        return o;
+    }
     template <bool TRAPS> RM_DI V4 eval(V3 p) const {
         const V3 l = local(p);
         V4 o;
@@ -640,6 +671,7 @@ struct SceneF {
         case RM_BODY_MENGER:     o = menger<TRAPS>(l); break;
         case RM_BODY_SIERPINSKI: o = sierpinski<TRAPS>(l); break;
         case RM_BODY_MANDELBULB: o = bulb<TRAPS, false>(l); break;
+        case RM_BODY_TERRAIN:    o = terrain(l); break;
         default:                 o = bulb<TRAPS, true>(l); break;
         }
         if (!unit) o.w = o.w * P0.ms;

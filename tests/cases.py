@@ -176,6 +176,36 @@ def _fractal(body, closeup, scale=None, rot=None, fscale=None, power=None):
     return f
 
 
+def _terrain(scale=1e-4, y0=-3.0, rot=None, floats=None):
+    """the terrain body (cginc:315-330 as a height field) under the default camera: slot 0 scaled so that the 30000-unit
+    heights and the 1.2e-5 noise frequency of the reference's formula land in the scene's range"""
+    def f(case, mat):
+        ts = scenes.default_transforms()
+        ts[0].position = np.asarray([0.0, y0, 0.0], dtype=F)
+        ts[0].lossyScale = np.asarray([scale, scale, scale], dtype=F)
+        if rot is not None:
+            ts[0].rotation = rot.astype(F)
+        _base(mat, case.w, case.h, transforms=ts)
+        mat.SetFloat("_RmSceneBody", 5.0)
+        for k, v in (floats or {}).items():
+            mat.SetFloat(k, v)
+    return f
+
+
+def _lit(floats, light_position=(-2.0, 6.0, -4.0), inner=None):
+    """helpers the reference defines and never calls (getbrightness*, getscatter, refract2) switched on, with the
+    `light l` of frag (shader:157-162) at _LightPosition"""
+    def f(case, mat):
+        if inner:
+            inner(case, mat)
+        else:
+            _base(mat, case.w, case.h)
+        mat.SetVector("_LightPosition", np.asarray(list(light_position) + [0.0], dtype=F))
+        for k, v in floats.items():
+            mat.SetFloat(k, v)
+    return f
+
+
 def _edge(floats=None, vectors=None):
     """default scene with degenerate uniforms"""
     def f(case, mat):
@@ -306,6 +336,17 @@ CASES = [
          setup=_fx({"_RmBounce": 1.0, "_RmShadowBias": 0.03}, inner=_transformed(False))),
     Case("shadowmap_lookup_persp_stress13_lowres_160x90", 160, 90, shadow=("persp", 64, 48), setup=_stress,
          prims=scenes.stress_primitives(13, seed=0x5EED000D)),
+    # terrain / noise / rand (cginc:125-149, 315-330) as a scene() body
+    Case("terrain_320x180", 320, 180, setup=_terrain()),
+    Case("terrain_rotated_nonuniform_200x112", 200, 112, setup=_terrain(scale=2e-4, y0=-4.0, rot=quat_angle_axis(12.0, (1, 0, 0.3)),
+                                                                        floats={"_StepFactor": 0.4})),
+    Case("terrain_shadow_dir_128x72", 128, 72, kind="shadow_dir", setup=lambda c, m: (_shadow_dir(c, m), _terrain()(c, m))),
+    # getbrightness / getbrightnesshard / getscatter / refract2 (shader:84-100, 129-147) wired in
+    Case("fx_getbrightness_240x135", 240, 135, setup=_lit({"_RmLightModel": 1.0})),
+    Case("fx_getbrightnesshard_240x135", 240, 135, setup=_lit({"_RmLightModel": 2.0}, light_position=(-3.0, 3.0, -2.5))),
+    Case("fx_getscatter_240x135", 240, 135, setup=_lit({"_RmScatter": 1.0}, light_position=(-3.0, 2.0, -3.0))),
+    Case("fx_refract2_bounce_scatter_transformed_200x112", 200, 112,
+         setup=_lit({"_RmBounce": 2.0, "_RefractiveIndex": 1.3, "_RmScatter": 1.0, "_RmLightModel": 1.0}, inner=_transformed(False))),
     Case("shadow_persp_100x100", 100, 100, kind="shadow_persp", setup=_shadow_persp),
     Case("shadow_dir_256x144", 256, 144, kind="shadow_dir", setup=_shadow_dir),
     # domain operators in front of scene()
@@ -386,7 +427,7 @@ def random_case(seed: int) -> Case:
     floats = {"_MaxSteps": float(int(20 + u() * 200)), "_MaxDist": float(F(10 + u() * 40)), "_StepFactor": float(F(0.3 + u() * 0.7)),
               "_NormalSampleScale": float(F(10 ** (-5 + 3 * u())))}
     if kind == 3:
-        floats["_RmSceneBody"] = float(1 + int(u() * 4))
+        floats["_RmSceneBody"] = float(1 + int(u() * 5))
         floats["_FractalScale"] = float(F(1.5 + u()))
         floats["_MaxSteps"] = float(int(20 + u() * 60))
     fx = u()
@@ -396,6 +437,12 @@ def random_case(seed: int) -> Case:
         floats["_RmBounce"] = 1.0
     elif fx < 0.3:
         floats["_RmDebugView"] = float(1 + int(u() * 3))
+    elif fx < 0.36:
+        floats["_RmLightModel"] = 1.0 if fx < 0.33 else 2.0
+    elif fx < 0.42:
+        floats["_RmScatter"] = 1.0
+    elif fx < 0.46:
+        floats["_RmBounce"], floats["_RefractiveIndex"] = 2.0, 1.25
     az, el, dist = u() * 2 * math.pi, (u() - 0.5) * 1.2, 4 + u() * 8
     pos = np.array([dist * math.cos(el) * math.sin(az), dist * math.sin(el), -dist * math.cos(el) * math.cos(az)])
     fov = 40 + u() * 60
@@ -426,6 +473,7 @@ def random_case(seed: int) -> Case:
                 t.lossyScale = np.asarray(sc, dtype=F)
         _base(mat, case.w, case.h, camera=cam, transforms=ts)
         mat.SetVector("_WorldSpaceLightPos0", np.asarray(light, dtype=F))
+        mat.SetVector("_LightPosition", np.asarray([2.5, 4.0, -3.0, 0.0], dtype=F))
         for k, v in floats.items():
             mat.SetFloat(k, v)
         if dom_op:

@@ -298,3 +298,65 @@ def test_unorm8_roundtrip_of_source_bytes(oracle, default_setup):
     assert out["stats"]["n_hit"] == 0
     assert np.array_equal(out["rgba"][..., :3], src[..., :3])
     assert (out["rgba"][..., 3] == 255).all()
+
+
+def test_rand_noise_terrain_closed_forms(oracle):          # cginc:125-149, 315-330
+    from oracle import numpy_restatement as NP
+    l = oracle.lib()
+    f2 = lambda x, y: fp(f32([x, y]))
+    # rand = frac(sin(dot(co, (12.9898, 78.233))) * 43758.5453) in [0, 1); rand((0,0)) = frac(sin(0) * c) = 0
+    assert l.rmo_rand(f2(0, 0)) == 0.0
+    for co in [(1, 0), (0, 1), (3, -7), (-12, 5), (101, 17)]:
+        want = math.sin(float(F(co[0]) * F(12.9898) + F(co[1]) * F(78.233)))
+        want = F(F(want) * F(43758.5453))
+        want = float(want - np.floor(want))
+        got = l.rmo_rand(f2(*co))
+        assert 0.0 <= got < 1.0 and got == pytest.approx(want, abs=1e-6)
+        assert got == float(NP.rand2(np.array([co[0]], F), np.array([co[1]], F))[0])
+    # noise at lattice points is the lattice value (f = 0 => u = 0); at the centre of a cell the mean of the corners
+    for i, j in [(0, 0), (2, 3), (-4, 1)]:
+        assert l.rmo_noise(f2(i, j)) == l.rmo_rand(f2(i, j))
+        a, b = l.rmo_rand(f2(i, j)), l.rmo_rand(f2(i + 1, j))
+        c, d = l.rmo_rand(f2(i, j + 1)), l.rmo_rand(f2(i + 1, j + 1))
+        assert l.rmo_noise(f2(i + .5, j + .5)) == pytest.approx((a + b + c + d) / 4, abs=2e-6)
+        assert l.rmo_noise(f2(i + .5, j)) == pytest.approx((a + b) / 2, abs=2e-6)
+    # terrain(0): p = 0 in all three octaves, noise(0) = rand(0) = 0 -> height 0
+    assert l.rmo_terrain(f2(0, 0)) == 0.0
+    # a general point, against the formula written out with the probes above: x = (1e5, 2e5) -> p = (1.2, 2.4) (float32)
+    x = np.array([1e5, 2e5], F)
+    p = x * F(0.003) / F(250)
+    a, b, dsum = F(0), F(1), F(0)
+    for _ in range(3):
+        n = F(l.rmo_noise(fp(p.copy())))
+        dsum = F(dsum + n)
+        a = F(a + F(b * n) / F(F(1) + F(F(dsum * dsum) + F(0))))
+        b = F(b * F(.5))
+        p = np.array([F(F(F(.8) * p[0]) * F(2)), F(F(F(-.6) * p[1]) * F(2))], F)
+    assert l.rmo_terrain(fp(x)) == float(F(F(30000.0) * a))
+    xs, ys = np.array([1e5, -3.3e4, 7.0], F), np.array([2e5, 9.1e4, -2.0], F)
+    got = NP.terrain_w(xs, ys)
+    assert [l.rmo_terrain(f2(float(u), float(v))) for u, v in zip(xs, ys)] == [float(g) for g in got]
+
+
+def test_light_helpers_closed_forms(oracle):               # shader:84-100, 129-147
+    l = oracle.lib()
+    lp = p3(0, 10, 0)
+    # light straight above a point whose normal points at it: dot(n, l - p) = 10 -> clamp -> 1
+    assert l.rmo_getbrightness(p3(0, 0, 0), p3(0, 1, 0), lp, 1) == pytest.approx(1.0 * (1 - 10 / 1000), rel=1e-6)      # hard: lerp(1, 0, dist/range)
+    assert l.rmo_getbrightness(p3(0, 0, 0), p3(0, 1, 0), lp, 0) == pytest.approx(1.0 * (1 - 10 / 1000), rel=1e-6)      # soft: (1*.5+.5)^2 = 1
+    assert l.rmo_getbrightness(p3(0, 0, 0), p3(0, -1, 0), lp, 1) == 0.0                                               # facing away
+    assert l.rmo_getbrightness(p3(0, 0, 0), p3(0, -1, 0), lp, 0) == 0.0                                               # (-1*.5+.5)^2 = 0
+    assert l.rmo_getbrightness(p3(0, 0, 0), p3(1, 0, 0), lp, 0) == pytest.approx(0.25 * 0.99, rel=1e-6)               # perpendicular: (.5)^2
+    assert l.rmo_getbrightness(p3(0, -990, 0), p3(0, 1, 0), lp, 0) == 0.0                                             # dist >= range
+    # getscatter: a ray along x passing the light at distance h: s = 1/h, integral = s * (atan((L + b) s) - atan(b s))
+    h, L = 2.0, 8.0
+    got = l.rmo_getscatter(p3(-3, 0, 0), p3(1, 0, 0), L, p3(0, h, 0))
+    want = (1 / h) * (math.atan((L - 3) / h) - math.atan(-3 / h))
+    assert got == pytest.approx(want, rel=2e-6)
+    assert l.rmo_c_atan(1.0) == float(F(math.pi / 4)) and l.rmo_c_atan(0.0) == 0.0
+    # refract2(i, n, eta): eta' = 2 - eta; i*eta' - n*(-cosi + eta'*cosi); eta = 1 leaves i unchanged
+    out = f32([0, 0, 0])
+    l.rmo_refract2(p3(0.6, -0.8, 0), p3(0, 1, 0), 1.0, fp(out))
+    assert out.tolist() == pytest.approx([0.6, -0.8, 0.0], abs=1e-7)
+    l.rmo_refract2(p3(0.6, -0.8, 0), p3(0, 1, 0), 1.5, fp(out))          # eta' = .5, cosi = -.8: i*.5 - n*(.8 - .4)
+    assert out.tolist() == pytest.approx([0.3, -0.8, 0.0], abs=1e-7)
