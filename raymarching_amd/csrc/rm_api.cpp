@@ -1100,6 +1100,26 @@ static int blit_host_common(rm_ctx *c, const uint8_t *src, const float *sdepth, 
     return RM_OK;
 }
 
+void *rm_host_alloc(rm_ctx *c, size_t bytes) {
+    try {
+        if (!c || bytes == 0) { (void)fail(c, RM_E_ARG, "rm_host_alloc: bad argument"); return nullptr; }
+        DeviceScope ds;
+        if (ds.enter(c->device) != hipSuccess) { (void)fail(c, RM_E_DEVICE, "rm_host_alloc: cannot select the context's device"); return nullptr; }
+        void *p = nullptr;
+        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) { (void)fail(c, RM_E_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); return nullptr; }
+        return p;
+    } catch (...) {
+        return nullptr;
+    }
+}
+
+void rm_host_free(rm_ctx *c, void *p) {
+    if (!c || !p) return;
+    DeviceScope ds;
+    if (ds.enter(c->device) == hipSuccess) (void)hipHostFree(p);
+}
+
 int rm_blit(rm_ctx *c, const uint8_t *src, const float *sdepth, uint8_t *rgba, float *depth, uint8_t *hit, int w, int h) {
     RM_TRY
     if (!c) return RM_E_ARG;

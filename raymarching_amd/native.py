@@ -56,6 +56,8 @@ SYMBOLS = [
     ("rm_has_property", C.c_int, [_P, C.c_char_p]),
     ("rm_set_texture_device", C.c_int, [_P, C.c_char_p, _P, C.c_int, C.c_int]),
     ("rm_set_primitives", C.c_int, [_P, C.POINTER(RmPrimitive), C.c_int]),
+    ("rm_host_alloc", _P, [_P, C.c_size_t]),
+    ("rm_host_free", None, [_P, _P]),
     ("rm_blit", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int]),
     ("rm_blit_device", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     ("rm_blit_steps", C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int]),

@@ -25,9 +25,8 @@ public class RaymarchingNative : MonoBehaviour
     Camera cam;
     RmMaterial native;
     Texture2D frame;
-    byte[] pixels;
-    float[] depth;
-    GCHandle pixelsPin, depthPin;
+    IntPtr pixels, depth;          // page-locked buffers from rm_host_alloc: the copies back run at PCIe rate
+    int frameBytes;
 
     void OnEnable()
     {
@@ -43,9 +42,12 @@ public class RaymarchingNative : MonoBehaviour
 
     void Release()
     {
-        if (pixelsPin.IsAllocated) pixelsPin.Free();
-        if (depthPin.IsAllocated) depthPin.Free();
-        pixels = null; depth = null;
+        if (native != null)
+        {
+            if (pixels != IntPtr.Zero) RmHip.rm_host_free(native.Ctx, pixels);
+            if (depth != IntPtr.Zero) RmHip.rm_host_free(native.Ctx, depth);
+        }
+        pixels = IntPtr.Zero; depth = IntPtr.Zero;
     }
 
     void Ensure(int w, int h)
@@ -53,10 +55,10 @@ public class RaymarchingNative : MonoBehaviour
         if (frame != null && frame.width == w && frame.height == h) return;
         Release();
         frame = new Texture2D(w, h, TextureFormat.RGBA32, false, true);   // linear: the project is in Gamma space
-        pixels = new byte[w * h * 4];
-        depth = new float[w * h];
-        pixelsPin = GCHandle.Alloc(pixels, GCHandleType.Pinned);
-        depthPin = GCHandle.Alloc(depth, GCHandleType.Pinned);
+        frameBytes = w * h * 4;
+        pixels = RmHip.rm_host_alloc(native.Ctx, (UIntPtr)(ulong)frameBytes);
+        depth = RmHip.rm_host_alloc(native.Ctx, (UIntPtr)(ulong)frameBytes);
+        if (pixels == IntPtr.Zero || depth == IntPtr.Zero) throw new InvalidOperationException("librmhip: " + RmHip.LastError(native.Ctx));
     }
 
     // un-normalised view-space rays through the four image corners, one per matrix row
@@ -106,8 +108,8 @@ public class RaymarchingNative : MonoBehaviour
 
         // no meshes in front of the march: no source image, no depth texture
         RmHip.Check(native.Ctx, RmHip.rm_blit(native.Ctx, IntPtr.Zero, IntPtr.Zero,
-                                             pixelsPin.AddrOfPinnedObject(), depthPin.AddrOfPinnedObject(), IntPtr.Zero, w, h));
-        frame.LoadRawTextureData(pixels);      // row 0 = bottom row, as Texture2D expects
+                                             pixels, depth, IntPtr.Zero, w, h));
+        frame.LoadRawTextureData(pixels, frameBytes);      // row 0 = bottom row, as Texture2D expects
         frame.Apply(false);
         Graphics.Blit(frame, dest);
     }

@@ -12,7 +12,9 @@ public static class RmHip
     public const int RM_SPHERE = 0, RM_BOX = 1, RM_LINK = 2, RM_CYLINDER = 3, RM_TORUS = 4;
     public const int RM_OP_SMAX = 1, RM_OP_NEGATE = 2;
     // values of the _RmSceneBody property
-    public const int RM_BODY_PRIMS = 0, RM_BODY_MENGER = 1, RM_BODY_SIERPINSKI = 2, RM_BODY_MANDELBULB = 3, RM_BODY_MANDELBROT = 4;
+    public const int RM_BODY_PRIMS = 0, RM_BODY_MENGER = 1, RM_BODY_SIERPINSKI = 2, RM_BODY_MANDELBULB = 3, RM_BODY_MANDELBROT = 4, RM_BODY_TERRAIN = 5;
+    // rm_set_kernel variants: 0 automatic, 1 tile, 2 persistent queue, 3 lane compaction, 4 tolerance kernel (not bit-exact)
+    public const int RM_KERNEL_AUTO = 0, RM_KERNEL_TILE = 1, RM_KERNEL_QUEUE = 2, RM_KERNEL_STREAM = 3, RM_KERNEL_FAST = 4;
 
     [StructLayout(LayoutKind.Sequential)]
     public struct Primitive
@@ -50,6 +52,24 @@ public static class RmHip
                                                       IntPtr dstRgba8, IntPtr dstDepth, IntPtr dstHit, int w, int h);
     [DllImport(Lib)] public static extern int rm_blit_device(IntPtr ctx, IntPtr dSrc, IntPtr dSceneDepth,
                                                              IntPtr dRgba8, IntPtr dDepth, IntPtr dHit, int w, int h, IntPtr hipStream);
+    [DllImport(Lib)] public static extern int rm_blit_device_noalloc(IntPtr ctx, IntPtr dSrc, IntPtr dSceneDepth,
+                                                                     IntPtr dRgba8, IntPtr dDepth, IntPtr dHit, int w, int h, IntPtr hipStream);
+    // dstSteps: two ushort per pixel (primary, shadow evaluations)
+    [DllImport(Lib)] public static extern int rm_blit_steps(IntPtr ctx, IntPtr srcRgba8, IntPtr sceneDepth,
+                                                            IntPtr dstRgba8, IntPtr dstDepth, IntPtr dstHit, IntPtr dstSteps, int w, int h);
+    [DllImport(Lib)] public static extern int rm_blit_steps_device(IntPtr ctx, IntPtr dSrc, IntPtr dSceneDepth, IntPtr dRgba8, IntPtr dDepth,
+                                                                   IntPtr dHit, IntPtr dSteps, int w, int h, IntPtr hipStream);
+    // page-locked host memory for rm_blit's images (copies at PCIe rate instead of staged through pageable memory)
+    [DllImport(Lib)] public static extern IntPtr rm_host_alloc(IntPtr ctx, UIntPtr bytes);
+    [DllImport(Lib)] public static extern void rm_host_free(IntPtr ctx, IntPtr p);
+    // Material.SetTexture("_ShadowMap", ...) for a depth plane in HBM (w x h floats)
+    [DllImport(Lib)] public static extern int rm_set_texture_device(IntPtr ctx, string name, IntPtr dTexels, int w, int h);
+    // compact frame transport between GPUs: records of rm_tile_record_bytes() per 8x8 tile that holds a hit
+    [DllImport(Lib)] public static extern UIntPtr rm_tile_record_bytes();
+    [DllImport(Lib)] public static extern int rm_compact_frames_device(IntPtr ctx, IntPtr dRgba8, IntPtr dHit, int w, int h, int nFrames,
+                                                                       IntPtr dRecords, IntPtr dCount, IntPtr hipStream);
+    [DllImport(Lib)] public static extern int rm_expand_frames_device(IntPtr ctx, IntPtr dRecords, uint nRecords, IntPtr dSrcRgba8, IntPtr dDstRgba8,
+                                                                      int w, int h, int nFrames, IntPtr hipStream);
     [DllImport(Lib)] public static extern int rm_band_rows(int h, int bandRows, int part, int nParts);
     [DllImport(Lib)] public static extern int rm_blit_bands_device(IntPtr ctx, IntPtr dSrc, IntPtr dSceneDepth, IntPtr dRgba8, IntPtr dDepth,
                                                                    IntPtr dHit, int w, int h, int bandRows, int part, int nParts, IntPtr hipStream);

@@ -31,17 +31,62 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_defaults_are_the_serialized_material():
-    """Assets/Raymarching.mat:66-93"""
+    """Every default rm_create() sets, against literals copied from the reference's assets (cited per line).  The parity
+    tests feed the oracle from the product's own property bag, so a wrong default would be shared by both sides: this is
+    the test that would catch it."""
+    f32 = np.float32
     with Material() as m:
-        assert m.GetFloat("_MaxSteps") == 400.0
-        assert m.GetFloat("_MaxDist") == 50.0
-        assert m.GetFloat("_StepFactor") == pytest.approx(0.7)
-        assert m.GetFloat("_NormalSampleScale") == pytest.approx(5e-5)
-        assert m.GetFloat("_ContactThreshold") == pytest.approx(0.002)
-        assert m.GetFloat("_FractalScale") == 2.0
-        pos = m.GetMatrix("_Positions")
-        np.testing.assert_allclose(pos.GetRow(2)[:3], [-7.87, 0.0, 1.522], rtol=1e-7)
+        # Assets/Raymarching.mat m_Floats
+        mat_floats = {"_ContactThreshold": 0.002,      # Raymarching.mat:66
+                      "_FractalRotationX": 0.19,       # :71
+                      "_FractalRotationY": -0.26,      # :72
+                      "_FractalRotationZ": 0.14,       # :73
+                      "_FractalScale": 2.0,            # :74
+                      "_Glossiness": 0.2,              # :76
+                      "_MaxDist": 50.0,                # :78
+                      "_MaxSteps": 400.0,              # :79
+                      "_NormalSampleScale": 0.00005,   # :82
+                      "_Reflections": 3.12,            # :85
+                      "_RefractiveIndex": 1.0,         # :86
+                      "_StepFactor": 0.7}              # :93
+        for k, v in mat_floats.items():
+            assert m.GetFloat(k) == float(f32(v)), k
+        # Assets/Raymarching.mat m_Colors
+        assert m.GetVector("_Color1").tolist() == [1, 1, 1, 1]                            # Raymarching.mat:99
+        assert m.GetVector("_Color2").tolist() == [0.75, 0.5, 1, 1]                       # :100
+        assert m.GetVector("_LightPosition").tolist() == [0, 0, 0, 0]                     # :102
+        # Assets/Scenes/SampleScene.unity: the four "Position N" transforms in the order of the script's array (:242-246)
+        pos, rot, scl = m.GetMatrix("_Positions"), m.GetMatrix("_Rotations"), m.GetMatrix("_Scales")
+        want_pos = [(-0.584, 0.049, 0.602),      # Position 0, SampleScene.unity:360
+                    (-0.74, 0.929, 0.0),         # Position 1, :489
+                    (-7.87, 0.0, 1.522),         # Position 2, :390
+                    (-3.074, -0.087, 0.08)]      # Position 3, :139
+        for i in range(4):
+            assert pos.GetRow(i).tolist() == [float(f32(v)) for v in want_pos[i]] + [0.0], i   # Vector3 row -> w = 0
+            assert rot.GetRow(i).tolist() == [0, 0, 0, 1], i                              # :138, :359, :389, :488
+            assert scl.GetRow(i).tolist() == [1, 1, 1, 0], i                              # :140, :361, :391, :490
+        # Main Camera: position (2, 1, -11.01) (:222), identity rotation (:221), fov 80 (:196), near .3 / far 1000 (:194-195)
+        assert m.GetVector("_WorldSpaceCameraPos").tolist() == [2.0, 1.0, float(f32(-11.01)), 0.0]
+        assert m.GetVector("_ProjectionParams").tolist() == [1.0, float(f32(0.3)), 1000.0, float(f32(1.0) / f32(1000.0))]
+        c2w = m.GetMatrix("_CameraInvViewMatrix")               # TRS(pos, identity, 1) with the Z column negated
+        assert c2w.GetRow(0).tolist() == [1, 0, 0, 2.0] and c2w.GetRow(1).tolist() == [0, 1, 0, 1.0]
+        assert c2w.GetRow(2).tolist() == [0, 0, -1, float(f32(-11.01))] and c2w.GetRow(3).tolist() == [0, 0, 0, 1]
+        t = f32(np.tan(np.float64(f32(80.0) * f32(0.5) * f32(0.0174532924))))      # Mathf.Tan(fov/2 * Deg2Rad), Raymarching.cs:41
+        a = t * f32(16.0 / 9.0)
+        fc = m.GetMatrix("_FrustrumCorners")                     # rows TL, TR, BR, BL (Raymarching.cs:45-53)
+        assert fc.GetRow(0).tolist() == [-float(a), float(t), -1, 0] and fc.GetRow(1).tolist() == [float(a), float(t), -1, 0]
+        assert fc.GetRow(2).tolist() == [float(a), -float(t), -1, 0] and fc.GetRow(3).tolist() == [-float(a), -float(t), -1, 0]
+        assert m.GetVector("_BackgroundColor").tolist() == [float(f32(0.19215687)), float(f32(0.3019608)), float(f32(0.4745098)), 1.0]   # :182
+        # Directional Light rotation (0.9659258, 0, 0, 0.2588191) (:458) = 150 degrees about X: forward (0, -.5, -.8660254);
+        # _WorldSpaceLightPos0 points towards the light
         np.testing.assert_allclose(m.GetVector("_WorldSpaceLightPos0"), [0, .5, 0.8660254, 0], rtol=1e-7)
+        q = np.array([0.9659258, 0, 0, 0.2588191], dtype=np.float64)
+        fwd = np.array([2 * (q[0] * q[2] + q[3] * q[1]), 2 * (q[1] * q[2] - q[3] * q[0]), 1 - 2 * (q[0] ** 2 + q[1] ** 2)])
+        np.testing.assert_allclose(-fwd, m.GetVector("_WorldSpaceLightPos0")[:3], atol=2e-7)
+        # switches of this build: all off = the shader as it stands
+        for k in ("_RmSceneBody", "_RmFractalPower", "_RmStepHeat", "_RmDebugView", "_RmVolumetricLight", "_RmBounce", "_RmDomainOp",
+                  "_RmShadowMode", "_RmLightModel", "_RmScatter"):
+            assert m.GetFloat(k) == 0.0, k
 
 
 def test_property_bag_semantics():

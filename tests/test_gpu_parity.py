@@ -601,3 +601,30 @@ def test_shadow_map_wiring_of_the_script(oracle, torch_cuda, name):
             rm.bind()
             from raymarching_amd import Graphics
             Graphics.Blit(None, rt, mat)
+
+
+def test_host_blit_into_page_locked_buffers(oracle, torch_cuda):
+    """rm_blit into memory from rm_host_alloc (the buffers the C# component uses) equals the oracle's frame"""
+    import ctypes as C
+    from raymarching_amd import Material
+    case = cases.BY_NAME["default_src_depth_333x187"]
+    ref = cases.oracle_run(case, oracle)
+    w, h = case.w, case.h
+    with Material() as mat:
+        src, sd = case.bind(mat)
+        lib = mat._lib
+        n = w * h
+        bufs = [lib.rm_host_alloc(mat.handle, n * 4) for _ in range(4)] + [lib.rm_host_alloc(mat.handle, n)]
+        assert all(bufs)
+        psrc, psd, pc, pd, ph = bufs
+        C.memmove(psrc, src.ctypes.data, n * 4)
+        C.memmove(psd, sd.ctypes.data, n * 4)
+        for _ in range(2):
+            mat._ck(lib.rm_blit(mat.handle, psrc, psd, pc, pd, ph, w, h))
+        got = {"rgba": np.ctypeslib.as_array(C.cast(pc, C.POINTER(C.c_uint8)), shape=(h, w, 4)).copy(),
+               "depth": np.ctypeslib.as_array(C.cast(pd, C.POINTER(C.c_float)), shape=(h, w)).copy(),
+               "hit": np.ctypeslib.as_array(C.cast(ph, C.POINTER(C.c_uint8)), shape=(h, w)).copy()}
+        for b in bufs:
+            lib.rm_host_free(mat.handle, b)
+        assert lib.rm_host_alloc(mat.handle, 0) is None
+    assert_frame_equal(got, ref, "pinned host buffers")
