@@ -412,6 +412,14 @@ def run_single(args) -> None:
         sec["stress256_1080p"] = {"what": "256 smooth-union primitives (rotated, scaled), _MaxSteps 512, grazing camera, 1920x1080",
                                   "ms_per_step": ms, "Mrays_per_s": rays(s5) / (ms * 1e-3) / 1e6, "flops_per_eval": per_eval,
                                   "tflops": fl5 / (ms * 1e-3) / 1e12, "frac_of_peak": fl5 / (ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS}
+        # the tolerance kernel on the same scene: per-step culling against bounding spheres (frames not bit-equal)
+        for tag, slack, fastm in (("cull_default_slack_strict_math", None, 0.0), ("cull_slack1_fast_math", 1.0, 1.0)):
+            m5.set_kernel(4)
+            m5.SetFloat("_RmCullSlack", -1.0 if slack is None else slack)
+            m5.SetFloat("_RmCullFastMath", fastm)
+            el, msc = timed(torch, step5, 3, 1)
+            sec["stress256_1080p"][tag] = {"ms_per_step": msc, "speedup_vs_exact": ms / msc,
+                                           "frac_of_peak": fl5 / (msc * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS}
         m5.close()
         del f5
 

@@ -460,19 +460,51 @@ int build_params(rm_ctx *c, RmParams *U, hipStream_t stream) {
             U->tail_ops = tail;
             flags |= RM_SF_CSG;
         }
+        // behind the table: a bounding sphere per primitive and its scale ratio, for the tolerance kernel's culling
+        const size_t extra16 = n + (n + 3) / 4;
         if (c->prims_dirty || !c->d_prims) {
-            int rc = ensure_cap(c, &c->d_prims, &c->d_prims_cap, n * sizeof(RmPrimDev));
+            std::vector<float> extra(extra16 * 4, 0.0f);
+            for (size_t i = 0; i < n; i++) {
+                const rm_primitive &p = c->prims[i];
+                float rl;                                          // radius about the local origin that holds the primitive
+                switch (p.type) {
+                case RM_SPHERE:   rl = std::fabs(p.params[0]) * .5f; break;
+                case RM_BOX:      rl = .5f * std::sqrt(p.params[0] * p.params[0] + p.params[1] * p.params[1] + p.params[2] * p.params[2]); break;
+                case RM_LINK:     rl = std::fabs(p.params[0]) + std::fabs(p.params[1]) + std::fabs(p.params[2]); break;
+                case RM_CYLINDER: rl = std::sqrt(p.params[0] * p.params[0] + p.params[1] * p.params[1]); break;
+                default:          rl = std::fabs(p.params[0]) + std::fabs(p.params[1]); break;
+                }
+                const float sx = std::fabs(p.scale[0]), sy = std::fabs(p.scale[1]), sz = std::fabs(p.scale[2]);
+                const float smax = std::fmax(sx, std::fmax(sy, sz)), smin = std::fmin(sx, std::fmin(sy, sz));
+                extra[4 * i + 0] = p.pos[0]; extra[4 * i + 1] = p.pos[1]; extra[4 * i + 2] = p.pos[2];
+                extra[4 * i + 3] = rl * smax * 1.0001f;
+                const float ratio = smax / smin;
+                extra[4 * n + i] = (std::isfinite(ratio) && ratio >= 1.0f) ? ratio * 1.0001f : __builtin_inff();   // inf: never culled
+            }
+            const size_t bytes = n * sizeof(RmPrimDev) + extra16 * 16;
+            int rc = ensure_cap(c, (uint8_t **)&c->d_prims, &c->d_prims_cap, bytes);
             if (rc) return rc;
             // the table must be in place before any later launch reads it, and the
-            // host vector dies at return: a blocking copy, done only when the scene changed,
+            // host vectors die at return: blocking copies, done only when the scene changed,
             // after every earlier launch (on whatever stream) has finished with the old table
             if ((rc = wait_for_last(c))) return rc;
             RM_HIP(c, hipMemcpy(c->d_prims, t.data(), n * sizeof(RmPrimDev), hipMemcpyHostToDevice));
+            RM_HIP(c, hipMemcpy((uint8_t *)c->d_prims + n * sizeof(RmPrimDev), extra.data(), extra16 * 16, hipMemcpyHostToDevice));
             c->prims_dirty = false;
         }
         U->prim_table = c->d_prims;
         U->n_prims = (int)n;
         U->lds_prims = (n <= RM_LDS_PRIMS && getf(c, "_RmLdsTable", 1.0f) != 0.0f) ? (int)n : 0;
+        U->cull_extra16 = (int32_t)extra16;
+        U->cull_fast_math = getf(c, "_RmCullFastMath", 0.0f) != 0.0f ? 1 : 0;
+        {
+            // default slack: k * tree depth, the bound under which a skipped leaf provably cannot reach the root
+            int depth = 0;
+            while (((size_t)1 << depth) < n) depth++;
+            const float dflt = 0.5f * (float)depth + 0.01f;
+            const float user = getf(c, "_RmCullSlack", -1.0f);
+            U->cull_slack = user >= 0.0f ? user : dflt;
+        }
     }
     const int body = (int)getf(c, "_RmSceneBody", 0.0f);
     if (body != RM_BODY_PRIMS) {
@@ -755,8 +787,12 @@ int launch(rm_ctx *c, const RmParams &U, hipStream_t stream, WorkMem M, bool rec
     int kernel = forced ? c->kernel
                : ((U.n_prims > 0 || U.body != RM_BODY_PRIMS || U.mode != RM_MODE_FRAG) ? RM_KERNEL_TILE : RM_KERNEL_QUEUE);
     // the tolerance kernel exists for the reference's 4-slot scene only; anything else takes the automatic (exact) choice
-    if (kernel == RM_KERNEL_FAST && (U.n_prims > 0 || U.body != RM_BODY_PRIMS))
+    bool cull = false;
+    if (kernel == RM_KERNEL_FAST && (U.n_prims > 0 || U.body != RM_BODY_PRIMS)) {
+        // table scenes that are plain smooth unions and fit the LDS table get the culling kernel
+        cull = U.body == RM_BODY_PRIMS && U.n_prims > 0 && U.lds_prims == U.n_prims && !(U.scene_flags & RM_SF_CSG);
         kernel = (U.n_prims > 0 || U.body != RM_BODY_PRIMS || U.mode != RM_MODE_FRAG) ? RM_KERNEL_TILE : RM_KERNEL_QUEUE;
+    }
     if (U.body != RM_BODY_PRIMS && kernel == RM_KERNEL_STREAM) kernel = RM_KERNEL_QUEUE;      // no stream kernel for the fractal bodies
     if (U.mode == RM_MODE_FRAG && (U.fx_flags != 0 || U.fx_view != 0 || U.light_model != 0)) kernel = RM_KERNEL_TILE;   // the optional frag lines exist in the tile kernels only
     if (U.dom_op != RM_DOM_NONE) kernel = RM_KERNEL_TILE;                                          // and so do the domain operators
@@ -774,7 +810,10 @@ int launch(rm_ctx *c, const RmParams &U, hipStream_t stream, WorkMem M, bool rec
         rc = ensure_partials(c, M, n_blocks);
         if (rc) return rc;
         P.partials = *M.partials;
-        RM_HIP(c, rm_launch_tiles(P, stream));
+        const bool plain = U.fx_flags == 0 && U.fx_view == 0 && U.light_model == 0 && U.dom_op == RM_DOM_NONE && !U.dst_steps &&
+                           !(U.mode == RM_MODE_FRAG && U.shadow_mode != 0);
+        if (cull && plain) RM_HIP(c, rm_launch_cull_tiles(P, stream));
+        else RM_HIP(c, rm_launch_tiles(P, stream));
         c->last_blocks = n_blocks;
     }
     c->last_partials = *M.partials;

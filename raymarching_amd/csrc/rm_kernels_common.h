@@ -839,12 +839,13 @@ RM_DI void rm_stream_body(const RmParams &U, const S &sc) {
 // RM_LDS_PRIMS of them): every lane then reads the same record, which the LDS serves as a
 // broadcast into VGPRs -- no scalar-load latency per primitive and no SGPR operands in the
 // distance arithmetic.  Larger tables are read from global memory through the scalar cache.
-RM_DI RmLdsPrimPtr rm_stage_table(const RmParams &U, unsigned lds_word_offset) {
+// (extra16: 16-byte words that follow the table in device memory and are staged behind it: the culling kernel's bounding spheres)
+RM_DI RmLdsPrimPtr rm_stage_table(const RmParams &U, unsigned lds_word_offset, unsigned extra16 = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned s_dyn[];
     unsigned *base = s_dyn + lds_word_offset;
     const uint4 *src = reinterpret_cast<const uint4 *>(U.prim_table);
     uint4 *dst = reinterpret_cast<uint4 *>(base);
-    const unsigned n16 = (unsigned)U.lds_prims * (sizeof(RmPrimDev) / 16);
+    const unsigned n16 = (unsigned)U.lds_prims * (sizeof(RmPrimDev) / 16) + extra16;
     for (unsigned i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
     return (RmLdsPrimPtr)(base);

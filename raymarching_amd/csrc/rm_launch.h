@@ -40,3 +40,5 @@ hipError_t rm_launch_stream(const RmParams &U, unsigned blocks, hipStream_t stre
 // the persistent kernel with the march loops on the fast (tolerance, not bit-exact) distance evaluation; 4-slot scenes
 // only; same calling convention as rm_launch_queue
 hipError_t rm_launch_fast(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu);
+// the tolerance kernel for N-primitive smooth-union scenes (per-step culling against bounding spheres); tile-kernel grid
+hipError_t rm_launch_cull_tiles(const RmParams &U, hipStream_t stream);

@@ -48,7 +48,7 @@ def kernel_resources(lib: str):
 
 def short_name(mangled: str) -> str:
     """rm_queue_kernel4<true, 1> from _ZN12_GLOBAL__N_116rm_queue_kernel4ILb1ELi1EEEv8RmParams"""
-    m = re.search(r"\d+(rm_[a-z_]+[4NF]?(?:_fx|_fast)?)(?:ILb([01])ELi(\d)EE)?", mangled)
+    m = re.search(r"\d+(rm_[a-z_]+[4NF]?(?:_fx|_fast|_cull)?)(?:ILb([01])EL[ib](\d)EE)?", mangled)
     if not m:
         return mangled
     if m.group(2) is None:
