@@ -43,8 +43,8 @@ def main():
     if kr:
         js["resources"] = dict(zip(["vgpr", "agpr", "sgpr", "lds", "scratch", "grid_x", "grid_y", "grid_z", "wg_x"], kr[0]))
         lines.append(f"resources as rocprofv3 records them: {js['resources']}")
-        # rocprofv3's vgpr/sgpr columns are not the allocation: the code object's own metadata (.vgpr_count, .sgpr_count)
-        # is what bounds occupancy (512 VGPRs per SIMD lane: 4 waves need <= 128)
+        # rocprofv3's vgpr column is the allocation (the metadata's .vgpr_count rounded up to the granule of 8) divided by 2:
+        # 116 -> 120 -> 60.  Occupancy follows the code object's own metadata (512 VGPRs per SIMD lane: 4 waves need <= 128).
         try:
             sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
             import kernel_resources as KR
