@@ -461,6 +461,11 @@ def run_multi(args) -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # RCCL prints a version banner on stdout when its first communicator comes up: everything this process and its libraries
+    # write to fd 1 goes to stderr until the result line, which is then the only thing on stdout
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # before the first GPU call of this process
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
@@ -470,7 +475,7 @@ def run_multi(args) -> None:
     counts_group = dist.new_group(backend="gloo")               # record counts travel as host tensors
 
     from raymarching_amd import Material, Raymarching, ShadowMapDirectional, scenes
-    from raymarching_amd.distributed import TileGather, poses_of, render_frame_bands
+    from raymarching_amd.distributed import DenseFrames, TileGather, poses_of, render_frame_bands
     from raymarching_amd.material import _fp, _ptr, current_stream_handle
     from raymarching_amd.unity import Transform, vec3
 
@@ -504,11 +509,13 @@ def run_multi(args) -> None:
                         root=0, count_group=counts_group, depth=2)
 
     expand = [True]
+    store = DenseFrames(expand=lambda rec, n, dst: mat.expand_frames(rec, n, dst),
+                        update=None if args.full_expand else (lambda old, n_old, rec, n, dst: mat.update_frames(old, n_old, rec, n, dst)))
 
     def on_received_for(b):
         def on_received(p, records, n):
             if p != 0 and expand[0]:                     # the root's own frames are dense already
-                mat.expand_frames(records, n, dense[p, b * per:b * per + len(groups[b])])
+                store.deliver((p, b), records, n, dense[p, b * per:b * per + len(groups[b])])
         return on_received
 
     pending = []
@@ -617,7 +624,8 @@ def run_multi(args) -> None:
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{N_POSES} orbit poses of the default SampleScene at {w}x{h} per step, Raymarching.mat settings, primary + "
                                    "soft-shadow rays, pose k on rank k mod N, finished frames gathered to rank 0 as compact tile records "
-                                   "and expanded there into dense RGBA8 frames",
+                                   "and written there into dense RGBA8 frames that rank 0 keeps (" + ("every frame rewritten whole" if args.full_expand
+                                   else "after the first delivery only the tiles of the previous and the new records are written") + ")",
                        "width": w, "height": h, "poses": N_POSES, "rays_per_step": rays(st), "primary_rays": st["n_pixels"],
                        "shadow_rays": st["n_hit"], "pose_batches_per_rank": len(groups),
                        "parallelism": f"pose-sharded x{world}, RCCL point-to-point gather of hit tiles to rank 0 on a side stream, overlapped with rendering",
@@ -632,9 +640,11 @@ def run_multi(args) -> None:
                           "what": "the same poses rendered, frames left on the rank that rendered them"},
             "secondary": sec,
         }
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     mat.close()
     dist.destroy_process_group()
+    os.close(real_stdout)
 
 
 def main() -> None:
@@ -651,6 +661,8 @@ def main() -> None:
     ap.add_argument("--pose-batches", type=int, default=2, help="N > 1: rm_blit_poses_device calls per rank and step")
     ap.add_argument("--root-blocks-per-cu", type=int, default=0, help="N > 1: cap on resident render blocks per CU on rank 0 (0 = none; "
                     "measured on one GPU: a cap does not make room for the expansion kernels, it only slows the rendering)")
+    ap.add_argument("--full-expand", action="store_true", help="N > 1: rank 0 rewrites every dense frame whole at every delivery "
+                    "(rm_expand_frames_device) instead of updating the tiles that changed (rm_update_frames_device)")
     ap.add_argument("--force-multi", action="store_true", help="developer check: run the N > 1 code path with a single rank")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()

@@ -237,6 +237,13 @@ int rm_compact_frames_device(rm_ctx *ctx, const void *d_rgba8, const void *d_hit
                              void *d_records, void *d_count, void *hip_stream);
 int rm_expand_frames_device(rm_ctx *ctx, const void *d_records, uint32_t n_records, const void *d_src_rgba8,
                             void *d_dst_rgba8, int w, int h, int n_frames, void *hip_stream);
+/* A displaying GPU that keeps its dense frames from one delivery to the next need not rewrite them whole:
+ * rm_update_frames_device takes frames that an earlier rm_expand_frames_device / rm_update_frames_device call built
+ * from d_old_records (same background), puts the background back into the tiles those records name and writes
+ * d_new_records over the result.  The frames then equal what rm_expand_frames_device would build from d_new_records,
+ * byte for byte, with only the tiles of the two record sets written. */
+int rm_update_frames_device(rm_ctx *ctx, const void *d_old_records, uint32_t n_old, const void *d_new_records, uint32_t n_new,
+                            const void *d_src_rgba8, void *d_dst_rgba8, int w, int h, int n_frames, void *hip_stream);
 
 /* ---- counters -------------------------------------------------------------
  * No counterpart in the reference (its nearest thing is the commented-out

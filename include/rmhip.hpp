@@ -75,6 +75,9 @@ public:
     Vector4 GetVector(const char *n) { float a[4]; ck(rm_get_vector(ctx_, n, a)); return {a[0], a[1], a[2], a[3]}; }
     Matrix4x4 GetMatrix(const char *n) { Matrix4x4 m; ck(rm_get_matrix(ctx_, n, m.m.data())); return m; }
     bool HasProperty(const char *n) { return rm_has_property(ctx_, n) != 0; }
+    // Material.SetTexture for a texture that lives in device memory ("_ShadowMap": fp32 depths, row 0 = bottom row)
+    void SetTextureDevice(const char *n, const void *d_texels, int w, int h) { ck(rm_set_texture_device(ctx_, n, d_texels, w, h)); }
+    void set_kernel(int variant) { ck(rm_set_kernel(ctx_, variant)); }
     rm_stats stats() { rm_stats s; ck(rm_get_stats(ctx_, &s)); return s; }
     rm_ctx *handle() const { return ctx_; }
     void ck(int rc) const { if (rc != RM_OK) throw std::runtime_error(std::string("librmhip ") + std::to_string(rc) + ": " + rm_last_error(ctx_)); }
@@ -91,7 +94,32 @@ struct RenderTexture {
     RenderTexture(int w, int h) : width(w), height(h), color((size_t)w * h * 4), hit((size_t)w * h), depth((size_t)w * h) {}
 };
 
+// page-locked host memory from the library: rm_blit copies into it at the full PCIe rate
+template <class T> class PinnedBuffer {
+public:
+    PinnedBuffer(Material &m, size_t count) : mat_(m), n_(count), p_(static_cast<T *>(rm_host_alloc(m.handle(), count * sizeof(T)))) {
+        if (!p_) throw std::runtime_error(std::string("rm_host_alloc: ") + rm_last_error(m.handle()));
+    }
+    ~PinnedBuffer() { rm_host_free(mat_.handle(), p_); }
+    PinnedBuffer(const PinnedBuffer &) = delete;
+    PinnedBuffer &operator=(const PinnedBuffer &) = delete;
+    T *data() { return p_; }
+    size_t size() const { return n_; }
+private:
+    Material &mat_; size_t n_; T *p_;
+};
+
 struct Graphics {
+    // Graphics.Blit into device memory, asynchronous on hip_stream (a hipStream_t); any output but rgba8 may be null
+    static void BlitDevice(Material &mat, const void *d_src_rgba8, const void *d_scene_depth, void *d_rgba8, void *d_depth, void *d_hit,
+                           int w, int h, void *hip_stream) {
+        mat.ck(rm_blit_device(mat.handle(), d_src_rgba8, d_scene_depth, d_rgba8, d_depth, d_hit, w, h, hip_stream));
+    }
+    // the same for callers that must not allocate (graph capture, serving loops): working memory is a static device array
+    static void BlitDeviceNoAlloc(Material &mat, const void *d_src_rgba8, const void *d_scene_depth, void *d_rgba8, void *d_depth,
+                                  void *d_hit, int w, int h, void *hip_stream) {
+        mat.ck(rm_blit_device_noalloc(mat.handle(), d_src_rgba8, d_scene_depth, d_rgba8, d_depth, d_hit, w, h, hip_stream));
+    }
     // Graphics.Blit(src, dest, mat); src may be null (constant _BackgroundColor)
     static void Blit(const RenderTexture *src, RenderTexture &dest, Material &mat, const float *scene_depth = nullptr) {
         if (src && (src->width != dest.width || src->height != dest.height)) throw std::invalid_argument("src and dest sizes differ");

@@ -1311,6 +1311,27 @@ int rm_expand_frames_device(rm_ctx *c, const void *d_records, uint32_t n_records
     RM_CATCH(c)
 }
 
+int rm_update_frames_device(rm_ctx *c, const void *d_old_records, uint32_t n_old, const void *d_new_records, uint32_t n_new,
+                            const void *d_src_rgba8, void *d_dst_rgba8, int w, int h, int n_frames, void *hip_stream) {
+    RM_TRY
+    if (!c) return RM_E_ARG;
+    if (!d_dst_rgba8 || n_frames <= 0 || (n_old && !d_old_records) || (n_new && !d_new_records))
+        return fail(c, RM_E_ARG, "rm_update_frames_device: bad argument");
+    if (((uintptr_t)d_dst_rgba8 | (uintptr_t)d_old_records | (uintptr_t)d_new_records | (uintptr_t)d_src_rgba8) & 3u)
+        return fail(c, RM_E_ARG, "rm_update_frames_device: buffers must be 4-byte aligned");
+    int rc = check_size(c, w, h);
+    if (rc) return rc;
+    DeviceScope ds;
+    RM_HIP(c, ds.enter(c->device));
+    hipStream_t stream = (hipStream_t)hip_stream;
+    vec4 bg = getv(c, "_BackgroundColor");
+    const uint32_t bg8 = unorm8(bg[0]) | (unorm8(bg[1]) << 8) | (unorm8(bg[2]) << 16) | 0xFF000000u;
+    RM_HIP(c, rm_restore_tiles(d_old_records, n_old, w, h, (unsigned)n_frames, d_src_rgba8, bg8, d_dst_rgba8, stream));
+    RM_HIP(c, rm_expand_tiles(d_new_records, n_new, w, h, (unsigned)n_frames, d_dst_rgba8, stream));
+    return RM_OK;
+    RM_CATCH(c)
+}
+
 int rm_debug_counter_slots(rm_ctx *c, uint32_t *out, int max_words, int *words_per_slot, int *n_slots) {
     RM_TRY
     if (!c || !c->have_last) return fail(c, RM_E_ARG, "rm_debug_counter_slots: no blit has run");

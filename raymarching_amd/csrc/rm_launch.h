@@ -25,6 +25,8 @@ hipError_t rm_pack_rgb(const void *in, void *out, size_t n_pixels, bool unpack, 
 unsigned rm_record_words();
 hipError_t rm_compact_tiles(const void *rgba, const void *hit, int w, int h, unsigned n_frames, void *records, void *counter, hipStream_t stream);
 hipError_t rm_expand_tiles(const void *records, unsigned n_records, int w, int h, unsigned n_frames, void *rgba, hipStream_t stream);
+hipError_t rm_restore_tiles(const void *records, unsigned n_records, int w, int h, unsigned n_frames, const void *src_rgba8, uint32_t bg8,
+                            void *rgba, hipStream_t stream);
 hipError_t rm_fill_from_src(const void *src_rgba8, void *dst_rgba8, size_t pixels_per_frame, unsigned n_frames, hipStream_t stream);
 hipError_t rm_reduce_stats(const unsigned *partials, unsigned n_blocks, unsigned long long *out, hipStream_t stream);
 

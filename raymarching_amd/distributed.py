@@ -264,10 +264,9 @@ class TileGather:
                         on_received(p, bufs.get(p), counts[p])
 
         if self.cuda:
-            ready = torch.cuda.Event()
-            ready.record()                      # everything enqueued so far, the compaction included
             with torch.cuda.stream(self.side):
-                self.side.wait_event(ready)
+                # the batch's compaction and nothing later: rendering enqueued since submit() must not hold the transfer up
+                self.side.wait_event(t.count_ready)
                 transfer()
                 ev = torch.cuda.Event()
                 ev.record()
@@ -282,3 +281,36 @@ class TileGather:
     def drain(self) -> None:
         if self.cuda:
             torch.cuda.current_stream(self.device).wait_stream(self.side)
+
+
+class DenseFrames:
+    """The displaying rank's dense frames, kept from one delivery to the next.  The first delivery into a slot builds the
+    frames whole (expand: rm_expand_frames_device); later ones only put the background back where the slot's previous
+    records wrote and write the new records (update: rm_update_frames_device), so the root's memory traffic per step is
+    the hit tiles', not the frames'.
+
+        store = DenseFrames(expand=lambda rec, n, dst: mat.expand_frames(rec, n, dst),
+                            update=lambda old, n_old, rec, n, dst: mat.update_frames(old, n_old, rec, n, dst))
+        store.deliver(key, records, n, dst)       # e.g. from TileGather's on_received; key names the slot (rank, batch)
+
+    The store keeps a reference to the records of the latest delivery per slot; callers must not overwrite them.
+    """
+
+    def __init__(self, expand: Callable, update: Optional[Callable] = None):
+        self.expand, self.update = expand, update
+        self.shown = {}
+
+    def deliver(self, key, records, n: int, dst) -> None:
+        prev = self.shown.get(key)
+        if prev is not None and self.update is not None:
+            self.update(prev[0], prev[1], records, n, dst)
+        else:
+            self.expand(records, n, dst)
+        self.shown[key] = (records, n)
+
+    def forget(self, key=None) -> None:
+        """the frames of `key` (or all) were overwritten by something else: the next delivery builds them whole"""
+        if key is None:
+            self.shown.clear()
+        else:
+            self.shown.pop(key, None)

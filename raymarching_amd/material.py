@@ -166,6 +166,14 @@ class Material:
                                                    _ptr(dst), w, h, n,
                                                    stream if stream is not None else current_stream_handle(dst.device)))
 
+    def update_frames(self, old_records, n_old: int, new_records, n_new: int, dst, src=None, stream=None) -> None:
+        """dst [n,h,w,4] was built from old_records by expand_frames/update_frames; afterwards it is what expand_frames
+        builds from new_records, with only the tiles of the two record sets written (rm_update_frames_device)"""
+        n, h, w = int(dst.shape[0]), int(dst.shape[1]), int(dst.shape[2])
+        self._ck(self._lib.rm_update_frames_device(self._ctx, _ptr(old_records) if n_old else None, int(n_old),
+                                                   _ptr(new_records) if n_new else None, int(n_new), _ptr(src), _ptr(dst), w, h, n,
+                                                   stream if stream is not None else current_stream_handle(dst.device)))
+
     def set_kernel(self, variant: int) -> None:
         self._ck(self._lib.rm_set_kernel(self._ctx, int(variant)))
 

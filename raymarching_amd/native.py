@@ -75,6 +75,7 @@ SYMBOLS = [
     ("rm_tile_record_bytes", C.c_size_t, []),
     ("rm_compact_frames_device", C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     ("rm_expand_frames_device", C.c_int, [_P, _P, C.c_uint32, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    ("rm_update_frames_device", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     ("rm_get_stats", C.c_int, [_P, C.POINTER(RmStats)]),
     ("rm_debug_counter_slots", C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("rm_set_kernel", C.c_int, [_P, C.c_int]),

@@ -70,6 +70,8 @@ public static class RmHip
                                                                        IntPtr dRecords, IntPtr dCount, IntPtr hipStream);
     [DllImport(Lib)] public static extern int rm_expand_frames_device(IntPtr ctx, IntPtr dRecords, uint nRecords, IntPtr dSrcRgba8, IntPtr dDstRgba8,
                                                                       int w, int h, int nFrames, IntPtr hipStream);
+    [DllImport(Lib)] public static extern int rm_update_frames_device(IntPtr ctx, IntPtr dOldRecords, uint nOld, IntPtr dNewRecords, uint nNew,
+                                                                      IntPtr dSrcRgba8, IntPtr dDstRgba8, int w, int h, int nFrames, IntPtr hipStream);
     [DllImport(Lib)] public static extern int rm_band_rows(int h, int bandRows, int part, int nParts);
     [DllImport(Lib)] public static extern int rm_blit_bands_device(IntPtr ctx, IntPtr dSrc, IntPtr dSceneDepth, IntPtr dRgba8, IntPtr dDepth,
                                                                    IntPtr dHit, int w, int h, int bandRows, int part, int nParts, IntPtr hipStream);

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Developer tool: what the gather costs rank 0 of an 8-GPU run of the batched-pose configuration, on one GPU.  Per step
 the main stream renders this rank's 8 poses (two batches of 4 at 7680x4320); a side stream expands the records of the 56
-poses the other ranks would have sent (stand-ins: this rank's own records, reused) into dense frames.
+poses the other ranks would have sent (stand-ins: this rank's own records, reused) into dense frames, either whole
+(rm_expand_frames_device) or by updating the tiles that changed (rm_update_frames_device).
     python scripts/dev_root_overlap.py [blocks_per_cu ...]"""
 import os
 import sys
@@ -38,6 +39,7 @@ def run(cap, expand, steps=4):
     bench.blit_poses(mat, fcs, c2ws, pos, frames[0], w, h, stream)
     mat.compact_frames(frames[0].color, frames[0].hit, records, count)
     n = int(count.item())
+    peer = records[:n].clone()                               # what a peer sent: not touched by this rank's compactions
 
     def step():
         for b in range(2):
@@ -47,7 +49,10 @@ def run(cap, expand, steps=4):
             if expand:
                 with torch.cuda.stream(side):
                     for _ in range(7):                       # 7 peers x 4 poses per batch
-                        mat.expand_frames(records, n, dense, stream=side.cuda_stream)
+                        if expand == 1:
+                            mat.expand_frames(peer, n, dense, stream=side.cuda_stream)
+                        else:
+                            mat.update_frames(peer, n, peer, n, dense, stream=side.cuda_stream)
 
     step()
     torch.cuda.synchronize()
@@ -61,6 +66,8 @@ def run(cap, expand, steps=4):
 
 
 for cap in [int(a) for a in sys.argv[1:]] or [0, 3]:
-    a, n = run(cap, False)
-    b, _ = run(cap, True)
-    print(f"blocks/CU cap {cap}: 8 poses {a * 1e3:.2f} ms; with 56 expansions ({n} records per 4 poses) on a side stream {b * 1e3:.2f} ms", flush=True)
+    a, n = run(cap, 0)
+    b, _ = run(cap, 1)
+    c, _ = run(cap, 2)
+    print(f"blocks/CU cap {cap}: 8 poses {a * 1e3:.2f} ms; with 56 full expansions ({n} records per 4 poses) on a side stream {b * 1e3:.2f} ms; "
+          f"with 56 updates (old tiles restored, new records written) {c * 1e3:.2f} ms", flush=True)

@@ -79,3 +79,22 @@ def expand_frames_numpy(records: np.ndarray, n: int, h: int, w: int, background)
         hh, ww = min(8, h - j * 8), min(8, w - i * 8)
         frames[f, j * 8:j * 8 + hh, i * 8:i * 8 + ww, :3] = px[:hh, :ww]
     return frames
+
+
+def update_frames_numpy(frames: np.ndarray, old_records: np.ndarray, new_records: np.ndarray, background) -> None:
+    """in place: the tiles the old records name go back to the background, then the new records are written"""
+    n, h, w = frames.shape[:3]
+    bg = np.asarray(background, dtype=np.uint8)
+    tx, ty = (w + 7) // 8, (h + 7) // 8
+    for rec in np.ascontiguousarray(old_records).view(np.uint32):
+        f, t2 = divmod(int(rec[0]), tx * ty)
+        j, i = divmod(t2, tx)
+        sl = (f, slice(j * 8, j * 8 + 8), slice(i * 8, i * 8 + 8))
+        frames[sl] = bg if bg.ndim == 1 else bg[sl[1:]]
+        frames[sl][..., 3] = 255
+    for rec in np.ascontiguousarray(new_records).view(np.uint32):
+        f, t2 = divmod(int(rec[0]), tx * ty)
+        j, i = divmod(t2, tx)
+        px = np.ascontiguousarray(rec[1:]).view(np.uint8).reshape(8, 8, 3)
+        hh, ww = min(8, h - j * 8), min(8, w - i * 8)
+        frames[f, j * 8:j * 8 + hh, i * 8:i * 8 + ww, :3] = px[:hh, :ww]

@@ -151,6 +151,33 @@ def _worker(rank, world, port, out_dir):
                     assert np.array_equal(delivered[k], ref), f"pose {k} differs after the compact gather"
             else:
                 assert not delivered and tg.bytes_sent == (rep + 1) * counts[rank] * RECORD_WORDS * 4
+        # ---- the root keeps its dense frames: later deliveries into a slot update the tiles that changed ----------
+        from helpers import update_frames_numpy
+        dense = {p: np.zeros((len(D.poses_of(n_poses, p, world)), h, w, 4), dtype=np.uint8) for p in range(world)}
+        calls = []
+
+        def expand_np(rec, n, dst):
+            calls.append("expand")
+            dst[...] = expand_frames_numpy(rec[:n].numpy(), dst.shape[0], h, w, bg)
+
+        def update_np(old, n_old, rec, n, dst):
+            calls.append("update")
+            update_frames_numpy(dst, old[:n_old].numpy(), rec[:n].numpy(), bg)
+
+        store = D.DenseFrames(expand_np, update_np)
+        for rep, shift in enumerate((0, 7, 3)):                       # three deliveries of different poses into the same slots
+            rendered = [O.render(O.Uniforms(pose_props(k + shift)), w, h, threads=1) for k in mine]
+            fr = torch.from_numpy(np.stack([r["rgba"] for r in rendered]))
+            ht = torch.from_numpy(np.stack([r["hit"] for r in rendered]))
+            t = tg.submit(fr, ht)
+            tg.complete(t, lambda p, records, n: store.deliver(p, records.clone(), n, dense[p]))
+            tg.drain()
+            if rank == 0:
+                assert calls == ["expand"] * world + ["update"] * (world * rep)
+                for p in range(world):
+                    for i, k in enumerate(D.poses_of(n_poses, p, world)):
+                        ref = O.render(O.Uniforms(pose_props(k + shift)), w, h, threads=2)["rgba"]
+                        assert np.array_equal(dense[p][i], ref), f"delivery {rep}: pose {k + shift} differs after the update"
         open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()

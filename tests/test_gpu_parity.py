@@ -571,6 +571,61 @@ def test_compact_transport_all_hit_and_no_hit(torch_cuda, w, h):
         assert bool((back.view(-1, 4) == torch.tensor([255, 128, 0, 255], dtype=torch.uint8, device=dev)).all())
 
 
+@pytest.mark.parametrize("name,with_src", [("default_640x360", False), ("default_src_depth_333x187", True), ("tiny_17x3", False)])
+def test_update_frames_equals_expand(torch_cuda, name, with_src):
+    """a displaying GPU that keeps its dense frames: update(old records -> new records) leaves byte for byte what a
+    full expansion of the new records builds, for hit regions that shrink, grow and vanish, with and without a source
+    image; the pixels outside the two record sets are never written"""
+    torch = torch_cuda
+    from helpers import RECORD_WORDS
+    from raymarching_amd import Material
+    from raymarching_amd.material import _ptr, current_stream_handle
+    case = cases.BY_NAME[name]
+    dev = "cuda:0"
+    w, h, n = case.w, case.h, 2
+    tiles = ((w + 7) // 8) * ((h + 7) // 8) * n
+    with Material() as mat:
+        src, _ = case.bind(mat)
+        dsrc = torch.from_numpy(src).to(dev) if (src is not None and with_src) else None
+        depth = torch.zeros((h, w), dtype=torch.float32, device=dev)
+        sets = []
+        for dists in ((50.0, 9.0), (6.0, 50.0), (0.5, 0.5), (50.0, 50.0)):      # the last but one: nothing is hit
+            frames = torch.zeros((n, h, w, 4), dtype=torch.uint8, device=dev)
+            hit = torch.zeros((n, h, w), dtype=torch.uint8, device=dev)
+            for f in range(n):
+                mat.SetFloat("_MaxDist", dists[f])
+                mat._ck(mat._lib.rm_blit_device(mat.handle, _ptr(dsrc), None, _ptr(frames[f]), _ptr(depth), _ptr(hit[f]), w, h,
+                                                current_stream_handle(dev)))
+            rec = torch.zeros((tiles, RECORD_WORDS), dtype=torch.int32, device=dev)
+            cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+            mat.compact_frames(frames, hit, rec, cnt)
+            sets.append((frames, rec, int(cnt.item())))
+        assert sets[2][2] == 0 and sets[0][2] > 0 and sets[1][2] > 0
+        ids = [set(r[:k, 0].cpu().tolist()) for _, r, k in sets]
+        assert ids[0] != ids[1] and ids[1] != ids[3], "the record sets should name different tiles"
+        dense = torch.full((n, h, w, 4), 9, dtype=torch.uint8, device=dev)
+        mat.expand_frames(sets[0][1], sets[0][2], dense, src=dsrc)
+        torch.cuda.synchronize()
+        assert torch.equal(dense, sets[0][0])
+        for old, new in ((0, 1), (1, 3), (3, 2), (2, 0), (0, 0)):
+            mat.update_frames(sets[old][1], sets[old][2], sets[new][1], sets[new][2], dense, src=dsrc)
+            torch.cuda.synchronize()
+            assert torch.equal(dense, sets[new][0]), f"update {old} -> {new} differs from the frames the blit wrote"
+        # only the tiles of the two record sets are written
+        dense.fill_(7)
+        mat.update_frames(sets[1][1], sets[1][2], sets[1][1], sets[1][2], dense, src=dsrc)
+        torch.cuda.synchronize()
+        touched = (dense != 7).any(dim=-1)
+        tile_ids = sets[1][1][:sets[1][2], 0].cpu().numpy().astype(np.int64)
+        want = np.zeros((n, h, w), dtype=bool)
+        tx, ty = (w + 7) // 8, (h + 7) // 8
+        for t in tile_ids:
+            f, t2 = divmod(int(t), tx * ty)
+            j, i = divmod(t2, tx)
+            want[f, j * 8:j * 8 + 8, i * 8:i * 8 + 8] = True
+        assert not (touched.cpu().numpy() & ~want).any()
+
+
 @pytest.mark.parametrize("name", ["shadowmap_lookup_persp_320x180", "shadowmap_lookup_dir_320x180"])
 def test_shadow_map_wiring_of_the_script(oracle, torch_cuda, name):
     """Raymarching.OnRenderImage with the three lines the reference keeps commented out (Raymarching.cs:91-93) switched on:
