@@ -786,6 +786,7 @@ int launch(rm_ctx *c, const RmParams &U, hipStream_t stream, WorkMem M, bool rec
     const bool forced = c->kernel != RM_KERNEL_AUTO;
     int kernel = forced ? c->kernel
                : ((U.n_prims > 0 || U.body != RM_BODY_PRIMS || U.mode != RM_MODE_FRAG) ? RM_KERNEL_TILE : RM_KERNEL_QUEUE);
+    if (kernel == RM_KERNEL_COOP) kernel = RM_KERNEL_TILE;       // a tile kernel: the cooperative one where it applies (below)
     // the tolerance kernel exists for the reference's 4-slot scene only; anything else takes the automatic (exact) choice
     bool cull = false;
     if (kernel == RM_KERNEL_FAST && (U.n_prims > 0 || U.body != RM_BODY_PRIMS)) {
@@ -806,13 +807,18 @@ int launch(rm_ctx *c, const RmParams &U, hipStream_t stream, WorkMem M, bool rec
         else if (rc) return rc;
     }
     if (kernel == RM_KERNEL_TILE) {
-        unsigned n_blocks = rm_tile_blocks(U.w, U.rows, U.n_poses);
+        const bool plain = U.fx_flags == 0 && U.fx_view == 0 && U.light_model == 0 && U.dom_op == RM_DOM_NONE && !U.dst_steps &&
+                           !(U.mode == RM_MODE_FRAG && U.shadow_mode != 0);
+        // big plain-union tables: the four waves of a block share one 8x8 tile and split the table (same bits, waves that
+        // finish together, a four times shorter critical chain); rm_set_kernel(1) keeps the one-wave-per-tile kernel
+        const bool coop = plain && !cull && (c->kernel == RM_KERNEL_AUTO || c->kernel == RM_KERNEL_COOP) && U.body == RM_BODY_PRIMS &&
+                          U.n_prims >= RM_COOP_MIN_PRIMS && U.lds_prims == U.n_prims && !(U.scene_flags & RM_SF_CSG);
+        unsigned n_blocks = coop ? rm_coop_blocks(U.w, U.rows, U.n_poses) : rm_tile_blocks(U.w, U.rows, U.n_poses);
         rc = ensure_partials(c, M, n_blocks);
         if (rc) return rc;
         P.partials = *M.partials;
-        const bool plain = U.fx_flags == 0 && U.fx_view == 0 && U.light_model == 0 && U.dom_op == RM_DOM_NONE && !U.dst_steps &&
-                           !(U.mode == RM_MODE_FRAG && U.shadow_mode != 0);
         if (cull && plain) RM_HIP(c, rm_launch_cull_tiles(P, stream));
+        else if (coop) RM_HIP(c, rm_launch_coop_tiles(P, stream));
         else RM_HIP(c, rm_launch_tiles(P, stream));
         c->last_blocks = n_blocks;
     }
@@ -980,7 +986,7 @@ int rm_set_primitives(rm_ctx *c, const rm_primitive *prims, int n) {
 int rm_set_kernel(rm_ctx *c, int variant) {
     RM_TRY
     if (!c) return RM_E_ARG;
-    if (variant < RM_KERNEL_AUTO || variant > RM_KERNEL_FAST) return fail(c, RM_E_ARG, "unknown kernel variant");
+    if (variant < RM_KERNEL_AUTO || variant > RM_KERNEL_COOP) return fail(c, RM_E_ARG, "unknown kernel variant");
     c->kernel = variant;
     return RM_OK;
     RM_CATCH(c)

@@ -1,0 +1,113 @@
+// rm_k_coop.hip -- table scenes, one launch block per 8x8 pixel tile: the four waves of a block march the SAME 64 rays and
+// each evaluates a quarter of the primitive table.
+//
+// The scene value is the balanced pairwise smin tree over the table in index order (cginc:363 lifted to N leaves).  A chunk
+// of C = 2^k consecutive leaves that starts at a multiple of C is a subtree of that tree, so with C = pow2ceil(n) / 4 the
+// table splits into 3 or 4 chunks whose values S0..S3 meet in the top two levels: smin(smin(S0, S1), smin(S2, S3)), or
+// smin(smin(S0, S1), S2) when the last chunk is empty (an odd element is carried up unchanged).  Every wave evaluates its
+// chunk with the same code as the one-wave kernels, the four values go through LDS, and every wave finishes the tree
+// itself, so all four hold bit-identical march states and take every branch together.  Same operations in the same order
+// as the oracle: the frames are bit-identical to the other exact kernels'.
+//
+// Why: a 256-primitive evaluation is ~18 000 VALU instructions; with one wave per tile the longest tile of a frame is a
+// chain of up to 400 of them and the four waves of a 16x16 block finish far apart, which leaves wave slots empty (2.6 of 4
+// resident on average).  Here a block's waves finish together and the chain is four times shorter; the price is one
+// LDS exchange and one barrier per evaluation (a few dozen cycles against ~18 000).
+#include "rm_kernels_common.h"
+
+namespace {
+
+template <bool ROT, int SCL>
+struct SceneNCoop {
+    SceneN<ROT, SCL, true> part;          // this wave's chunk as a tree of its own
+    int n_chunks;                         // 3 or 4
+    unsigned wv, lane;
+    RM_LDS float *xw;                     // [2][4][64]: distances, double-buffered so that one barrier per evaluation is enough
+    RM_LDS float *x4;                     // [4][4][64]: rgb + distance of the colour evaluation (one per pixel)
+    mutable unsigned parity;
+
+    RM_DI float w(V3 p) const {
+        float mine = 0.0f;
+        if (part.n > 0) mine = part.w(p);
+        RM_LDS float *b = xw + parity * 256u;
+        b[wv * 64u + lane] = mine;
+        __syncthreads();
+        const float s0 = b[lane], s1 = b[64u + lane], s2 = b[128u + lane];
+        const float s01 = rm_smin_w(s0, s1);
+        float r;
+        if (n_chunks == 4) { const float s3 = b[192u + lane]; r = rm_smin_w(s01, rm_smin_w(s2, s3)); }
+        else r = rm_smin_w(s01, s2);
+        // the buffer written next is the other one: a wave that runs ahead cannot overwrite what a slower one still reads,
+        // because it meets that wave at the next barrier before it returns to this buffer
+        parity ^= 1u;
+        return r;
+    }
+    RM_DI float wm(V3 p) const { return w(p); }
+    RM_DI V4 full(V3 p) const {
+        V4 m; m.x = m.y = m.z = m.w = 0.0f;
+        if (part.n > 0) m = part.full(p);
+        RM_LDS float *b = x4 + wv * 256u;
+        b[lane] = m.x; b[64u + lane] = m.y; b[128u + lane] = m.z; b[192u + lane] = m.w;
+        __syncthreads();
+        V4 s[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            RM_LDS const float *q = x4 + k * 256;
+            s[k].x = q[lane]; s[k].y = q[64u + lane]; s[k].z = q[128u + lane]; s[k].w = q[192u + lane];
+        }
+        const V4 s01 = rm_smin4(s[0], s[1]);
+        if (n_chunks == 4) return rm_smin4(s01, rm_smin4(s[2], s[3]));
+        return rm_smin4(s01, s[2]);
+    }
+};
+
+template <bool ROT, int SCL>
+__global__ __launch_bounds__(256, 4) void rm_coop_kernelN(const RmParams U) {
+    __shared__ float s_xw[2 * 4 * 64];
+    __shared__ float s_x4[4 * 4 * 64];
+    PrimTable<true> t;
+    t.T = rm_stage_table(U, 0);                                           // ends with a __syncthreads()
+    const int tid = threadIdx.x;
+    const unsigned lane = tid & 63, wv = tid >> 6;
+    // chunk = pow2ceil(n) / 4, n >= 8
+    const int chunk = (1 << (32 - __builtin_clz((unsigned)U.n_prims - 1u))) >> 2;
+    const int lo = (int)wv * chunk;
+    int cnt = U.n_prims - lo;
+    cnt = cnt < 0 ? 0 : (cnt > chunk ? chunk : cnt);
+    PrimTable<true> tc;
+    tc.T = t.T + lo * (int)(sizeof(RmPrimDev) / 16);
+    SceneNCoop<ROT, SCL> sc{SceneN<ROT, SCL, true>(tc, cnt, false, 0u), (U.n_prims + chunk - 1) / chunk, wv, lane,
+                            (RM_LDS float *)s_xw, (RM_LDS float *)s_x4, 0u};
+    unsigned c_hit = 0, c_p = 0, c_s = 0;
+    const int x = blockIdx.x * 8 + (int)(lane & 7u), yl = blockIdx.y * 8 + (int)(lane >> 3);
+    if (x < U.w && yl < U.rows) {
+        PixelOut po = rm_compute_pixel(U, sc, x, yl, (int)blockIdx.z, c_hit, c_p, c_s);
+        if (wv == 0) rm_store_pixel(U, po);                               // the four waves hold the same pixels
+    }
+    if (wv == 0) {
+        c_hit = rm_wave_sum(c_hit); c_p = rm_wave_sum(c_p); c_s = rm_wave_sum(c_s);
+        const unsigned bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (lane < 3) U.partials[RM_SLOT_WORDS * bid + lane] = lane == 0 ? c_hit : lane == 1 ? c_p : c_s;
+    }
+}
+
+template <bool ROT, int SCL>
+hipError_t launch_coop_variant(const RmParams &U, dim3 grid, hipStream_t stream) {
+    hipLaunchKernelGGL((rm_coop_kernelN<ROT, SCL>), grid, dim3(256), (size_t)U.n_prims * sizeof(RmPrimDev), stream, U);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+unsigned rm_coop_blocks(int w, int rows, int n_poses) {
+    return (unsigned)((w + 7) / 8) * (unsigned)((rows + 7) / 8) * (unsigned)n_poses;
+}
+
+// table scenes without op bits, staged whole in LDS (U.lds_prims == U.n_prims), RM_COOP_MIN_PRIMS <= n
+hipError_t rm_launch_coop_tiles(const RmParams &U, hipStream_t stream) {
+    if (U.w <= 0 || U.rows <= 0 || U.n_poses <= 0 || U.n_prims < RM_COOP_MIN_PRIMS || U.lds_prims != U.n_prims ||
+        (U.scene_flags & RM_SF_CSG) || U.body != RM_BODY_PRIMS) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((U.w + 7) / 8), (unsigned)((U.rows + 7) / 8), (unsigned)U.n_poses);
+    if (grid.y > 65535u || grid.z > 65535u) return hipErrorInvalidValue;
+    RM_DISPATCH_VARIANT(launch_coop_variant, U, U, grid, stream);
+}

@@ -1,10 +1,10 @@
-// rm_launch.h -- host-callable launchers implemented in rm_k_tile.hip, rm_k_tile_fx.hip, rm_k_queue.hip, rm_k_stream.hip.
+// rm_launch.h -- host-callable launchers implemented in the rm_k_*.hip translation units.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "rm_device.h"
 
 // kernel variants selectable through rm_set_kernel()
-enum { RM_KERNEL_AUTO = 0, RM_KERNEL_TILE = 1, RM_KERNEL_QUEUE = 2, RM_KERNEL_STREAM = 3, RM_KERNEL_FAST = 4 };
+enum { RM_KERNEL_AUTO = 0, RM_KERNEL_TILE = 1, RM_KERNEL_QUEUE = 2, RM_KERNEL_STREAM = 3, RM_KERNEL_FAST = 4, RM_KERNEL_COOP = 5 };
 
 // one-thread-per-pixel tile kernel over U.w x U.rows x U.n_poses
 hipError_t rm_launch_tiles(const RmParams &U, hipStream_t stream);
@@ -44,3 +44,9 @@ hipError_t rm_launch_stream(const RmParams &U, unsigned blocks, hipStream_t stre
 hipError_t rm_launch_fast(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu);
 // the tolerance kernel for N-primitive smooth-union scenes (per-step culling against bounding spheres); tile-kernel grid
 hipError_t rm_launch_cull_tiles(const RmParams &U, hipStream_t stream);
+
+// exact kernel for table scenes: one block per 8x8 tile, its four waves share the tile's rays and split the table
+// (plain-union tables of at least RM_COOP_MIN_PRIMS primitives that are staged whole in LDS)
+#define RM_COOP_MIN_PRIMS 32
+unsigned rm_coop_blocks(int w, int rows, int n_poses);
+hipError_t rm_launch_coop_tiles(const RmParams &U, hipStream_t stream);

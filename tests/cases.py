@@ -282,6 +282,13 @@ CASES = [
     Case("tiny_17x3", 17, 3),
     Case("stress256_320x180", 320, 180, setup=_stress, prims=scenes.stress_primitives(256)),
     Case("stress13_200x112", 200, 112, setup=_stress, prims=scenes.stress_primitives(13, seed=0x5EED000D)),
+    # tables the cooperative kernel splits over four waves: 33 -> chunks of 16, 16, 1 (three chunks); 100 -> 32, 32, 32, 4;
+    # 64 untransformed primitives (the variant without rotation and scale); a depth pass over a table
+    Case("stress33_160x90", 160, 90, setup=_stress, prims=scenes.stress_primitives(33, seed=0x5EED0021)),
+    Case("stress100_160x90", 160, 90, setup=_stress, prims=scenes.stress_primitives(100, seed=0x5EED0064)),
+    Case("stress64_untransformed_160x90", 160, 90, setup=_stress,
+         prims=[dict(p, quat=(0.0, 0.0, 0.0, 1.0), scale=(1.0, 1.0, 1.0)) for p in scenes.stress_primitives(64, seed=0x5EED0040)]),
+    Case("stress48_shadow_dir_128x72", 128, 72, kind="shadow_dir", setup=_shadow_dir, prims=scenes.stress_primitives(48, seed=0x5EED0030)),
     Case("prims4_as_table_320x180", 320, 180, prims=[
         {"type": 0, "pos": (-0.584, 0.049, 0.602), "quat": (0, 0, 0, 1), "scale": (1, 1, 1), "color": (1, .25, .25), "params": (1,)},
         {"type": 1, "pos": (-0.74, 0.929, 0.0), "quat": (0, 0, 0, 1), "scale": (1, 1, 1), "color": (.25, 1, .25), "params": (1, 1, 1)},

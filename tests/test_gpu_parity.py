@@ -27,7 +27,7 @@ def torch_cuda():
     return torch
 
 
-KERNELS = {"tile": 1, "queue": 2, "stream": 3}
+KERNELS = {"tile": 1, "queue": 2, "stream": 3, "coop": 5}
 
 
 def gpu_run(case, torch, host_path=False, kernel=0, frames=1):
@@ -122,6 +122,30 @@ def test_gpu_equals_oracle(oracle, torch_cuda, name, kernel):
     assert got["stats"]["n_pixels"] == case.w * case.h
 
 
+COOP_CASES = [c.name for c in cases.CASES if not c.heavy and c.prims is not None and len(c.prims) >= 32]
+
+
+@pytest.mark.parametrize("kernel", ["coop", "auto"])
+@pytest.mark.parametrize("name", COOP_CASES + ["stress13_200x112", "default_640x360"])
+def test_cooperative_table_kernel_equals_oracle(oracle, torch_cuda, name, kernel):
+    """big plain-union tables: one block per 8x8 tile, the four waves share the tile's rays and split the table in aligned
+    power-of-two chunks (three or four of them, the last possibly partial), which are subtrees of the pairwise tree; the
+    frames and counters are the oracle's bit for bit.  It is the automatic choice for such tables; tables with op bits,
+    small tables and the 4-slot scene take the kernels they took before, also when the cooperative one is asked for"""
+    case = cases.BY_NAME[name]
+    ref = cases.oracle_run(case, oracle)
+    got = gpu_run(case, torch_cuda, kernel=KERNELS.get(kernel, 0))
+    if case.kind == "frag":
+        assert_frame_equal(got, ref, name)
+        assert got["stats"]["sum_steps_s"] == ref["stats"]["sum_steps_s"]
+    else:
+        assert np.array_equal(got["hit"], ref["hit"])
+        assert np.array_equal(got["depth"].view(np.uint32), ref["depth"].view(np.uint32))
+    assert got["stats"]["n_hit"] == int(ref["hit"].sum()) == int(got["hit"].sum())
+    assert got["stats"]["sum_steps_p"] == ref["stats"]["sum_steps_p"]
+    assert got["stats"]["n_pixels"] == case.w * case.h
+
+
 @pytest.mark.parametrize("kernel,frames", [("tile", 1), ("queue", 1), ("queue", 4), ("stream", 2)])
 @pytest.mark.parametrize("name", ["default_1920x1080", "default_3840x2160"])
 def test_gpu_full_size_matches_golden_hashes(torch_cuda, name, kernel, frames):
@@ -139,7 +163,8 @@ def test_gpu_full_size_matches_golden_hashes(torch_cuda, name, kernel, frames):
 
 @pytest.mark.parametrize("name,kernel", [("shadow_dir_3840x2160", "tile"), ("shadow_dir_3840x2160", "queue"),
                                          ("orbit_k17_7680x4320", "queue"), ("orbit_k17_7680x4320", "tile"),
-                                         ("stress256_1920x1080", "tile"), ("stress256_1920x1080", "queue")])
+                                         ("stress256_1920x1080", "tile"), ("stress256_1920x1080", "queue"),
+                                         ("stress256_1920x1080", "coop")])
 def test_gpu_benchmark_configurations_match_golden_hashes(torch_cuda, name, kernel):
     """the other benchmark configurations at full size against the oracle's committed hashes: the 4K
     directional depth pass, one 8K pose of the orbit, the 256-primitive scene at 1080p with 512 steps"""
