@@ -46,7 +46,7 @@ hipError_t rm_launch_fast(const RmParams &U, unsigned blocks, hipStream_t stream
 hipError_t rm_launch_cull_tiles(const RmParams &U, hipStream_t stream);
 
 // exact kernel for table scenes: one block per 8x8 tile, its four waves share the tile's rays and split the table
-// (plain-union tables of at least RM_COOP_MIN_PRIMS primitives that are staged whole in LDS)
+// (tables of at least RM_COOP_MIN_PRIMS primitives that are staged whole in LDS)
 #define RM_COOP_MIN_PRIMS 32
 unsigned rm_coop_blocks(int w, int rows, int n_poses);
 hipError_t rm_launch_coop_tiles(const RmParams &U, hipStream_t stream);

@@ -47,23 +47,28 @@ def kernel_resources(lib: str):
 
 
 def short_name(mangled: str) -> str:
-    """rm_queue_kernel4<true, 1> from _ZN12_GLOBAL__N_116rm_queue_kernel4ILb1ELi1EEEv8RmParams"""
-    m = re.search(r"\d+(rm_[a-z_]+[4NF]?(?:_fx|_fast|_cull)?)(?:ILb([01])EL[ib](\d)EE)?", mangled)
+    """rm_queue_kernel4<rot=1, scl=1> from _ZN12_GLOBAL__N_116rm_queue_kernel4ILb1ELi1EEEv8RmParams; further template
+    arguments are appended as they are (rm_coop_kernelN<rot=1, scl=1, 0>)"""
+    m = re.search(r"\d+(rm_[a-z_]+[4NF]?(?:_fx|_fast|_cull)?)(?:I((?:L[bi]\d+E)+)E)?", mangled)
     if not m:
         return mangled
     if m.group(2) is None:
         return m.group(1)
-    return f"{m.group(1)}<rot={m.group(2)}, scl={m.group(3)}>"
+    args = re.findall(r"L[bi](\d+)E", m.group(2))
+    names = ["rot=" + args[0]] + (["scl=" + args[1]] if len(args) > 1 else []) + args[2:]
+    return f"{m.group(1)}<{', '.join(names)}>"
 
 
 def short_name_from_demangled(name: str) -> str:
     """rm_queue_kernel4<rot=0, scl=0> from 'void (anonymous namespace)::rm_queue_kernel4<false, 0>(RmParams)'"""
-    m = re.search(r"(rm_[a-z_]+[4NF]?(?:_fx)?)(?:<(true|false), (\d)>)?", name)
+    m = re.search(r"(rm_[a-z_]+[4NF]?(?:_fx|_fast|_cull)?)(?:<([^>]*)>)?", name)
     if not m:
         return name
     if m.group(2) is None:
         return m.group(1)
-    return f"{m.group(1)}<rot={1 if m.group(2) == 'true' else 0}, scl={m.group(3)}>"
+    args = [{"true": "1", "false": "0"}.get(a.strip(), a.strip()) for a in m.group(2).split(",")]
+    names = ["rot=" + args[0]] + (["scl=" + args[1]] if len(args) > 1 else []) + args[2:]
+    return f"{m.group(1)}<{', '.join(names)}>"
 
 
 def main():

@@ -298,6 +298,9 @@ CASES = [
     Case("csg7_480x270", 480, 270, prims=scenes.csg_primitives()),
     Case("csg_random37_240x135", 240, 135, setup=_stress, prims=scenes.csg_random_primitives(37)),
     Case("csg_random70_160x90", 160, 90, setup=_stress, prims=scenes.csg_random_primitives(70, seed=0x5EED070)),
+    # op bits in tables the cooperative kernel splits: 64 = four full chunks, 100 = 32, 32, 32, 4 (37 and 70 above: three chunks)
+    Case("csg_random64_128x72", 128, 72, setup=_stress, prims=scenes.csg_random_primitives(64, seed=0x5EED064)),
+    Case("csg_random100_128x72", 128, 72, setup=_stress, prims=scenes.csg_random_primitives(100, seed=0x5EED100)),
     Case("menger_closeup_320x180", 320, 180, setup=_fractal(1, True)),
     Case("menger_scaled_rotated_256x144", 256, 144, setup=_fractal(1, False, scale=(3.0, 2.5, 3.5), rot=quat_angle_axis(33.0, (1, 2, 3)))),
     Case("sierpinski_closeup_320x180", 320, 180, setup=_fractal(2, True)),

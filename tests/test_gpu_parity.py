@@ -128,9 +128,9 @@ COOP_CASES = [c.name for c in cases.CASES if not c.heavy and c.prims is not None
 @pytest.mark.parametrize("kernel", ["coop", "auto"])
 @pytest.mark.parametrize("name", COOP_CASES + ["stress13_200x112", "default_640x360"])
 def test_cooperative_table_kernel_equals_oracle(oracle, torch_cuda, name, kernel):
-    """big plain-union tables: one block per 8x8 tile, the four waves share the tile's rays and split the table in aligned
-    power-of-two chunks (three or four of them, the last possibly partial), which are subtrees of the pairwise tree; the
-    frames and counters are the oracle's bit for bit.  It is the automatic choice for such tables; tables with op bits,
+    """big tables: one block per 8x8 tile, the four waves share the tile's rays and split the table in aligned
+    power-of-two chunks (three or four of them, the last possibly partial), which are subtrees of the pairwise tree (smax
+    nodes included); the frames and counters are the oracle's bit for bit.  It is the automatic choice for such tables;
     small tables and the 4-slot scene take the kernels they took before, also when the cooperative one is asked for"""
     case = cases.BY_NAME[name]
     ref = cases.oracle_run(case, oracle)
