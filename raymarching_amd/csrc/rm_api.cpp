@@ -698,7 +698,8 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, int family, WorkMem
     const float cap_per_cu = getf(c, "_RmBlocksPerCU", 0.0f);      // 0: as many as fit
     if (cap_per_cu >= 1.0f && (unsigned)cap_per_cu < per_cu) per_cu = (unsigned)cap_per_cu;
     unsigned resident = (unsigned)c->n_cus * per_cu;
-    unsigned want = (n_tiles + 3) / 4;
+    // a workgroup renders four tiles at a time (one per wave), or one where its waves share a tile's rays
+    unsigned want = (streamk && rm_stream_is_coop(P)) ? n_tiles : (n_tiles + 3) / 4;
     unsigned blocks = want < resident ? want : resident;
     // static share: a fraction of the tiles, dealt evenly over the waves that will not start on a
     // heavy tile (at most heavy_cap of them do; the kernel uses the exact count)

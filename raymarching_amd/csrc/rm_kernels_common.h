@@ -685,14 +685,19 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
 #endif
 enum { RM_PH_IDLE = 0, RM_PH_PRIMARY = 1, RM_PH_TAP = 2, RM_PH_WAITCOL = 3, RM_PH_SHADOW = 4 };
 
-template <class S>
+// COOP: the four waves of a workgroup carry the SAME 64 rays (the scene object splits every evaluation between them,
+// rm_coop.h): the workgroup is the unit that owns a tile, its waves take every branch together, wave 0 writes.
+template <bool COOP = false, class S>
 RM_DI void rm_stream_body(const RmParams &U, const S &sc) {
     const RmQueue &Q = U.queue;
     const int lane = threadIdx.x & 63;
-    const unsigned gw = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const unsigned n_waves = (gridDim.x * blockDim.x) >> 6;
+    const bool writer = !COOP || (threadIdx.x >> 6) == 0;
+    __shared__ unsigned s_claim[2];
+    unsigned claim_parity = 0;
+    const unsigned gw = COOP ? blockIdx.x : __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const unsigned n_waves = COOP ? gridDim.x : (gridDim.x * blockDim.x) >> 6;
     unsigned *counter = Q.counters + Q.cnt_cur * RM_Q_SHARDS * RM_Q_STRIDE;
-    if (gw == 0 && lane < RM_Q_SHARDS) Q.counters[(Q.cnt_clr * RM_Q_SHARDS + lane) * RM_Q_STRIDE] = 0u;
+    if (gw == 0 && writer && lane < RM_Q_SHARDS) Q.counters[(Q.cnt_clr * RM_Q_SHARDS + lane) * RM_Q_STRIDE] = 0u;
 
     const float sf = rm_vgpr(U.step_factor), kc = rm_vgpr(.0025f), eps = rm_vgpr(U.nss);
     const V3 L = mk3(rm_vgpr(U.light[0]), rm_vgpr(U.light[1]), rm_vgpr(U.light[2]));
@@ -726,7 +731,7 @@ RM_DI void rm_stream_body(const RmParams &U, const S &sc) {
                         phase = RM_PH_IDLE;
                         PixelOut po; po.oidx = oidx; po.depth = 0.0f; po.hit = 0;
                         po.rgba = U.src ? (reinterpret_cast<const uint32_t *>(U.src)[gidx] | 0xFF000000u) : U.bg_rgba8;
-                        rm_store_pixel(U, po);
+                        if (writer) rm_store_pixel(U, po);
                     }
                 }
             }
@@ -735,7 +740,15 @@ RM_DI void rm_stream_body(const RmParams &U, const S &sc) {
             next_px += taken;
             if (next_px == 64u) {
                 unsigned kq = 0;
-                if (lane == 0) kq = atomicAdd(counter, 1u);
+                if (COOP) {
+                    // one claim per workgroup, handed to its waves through LDS; the slot alternates, so one barrier is enough
+                    if (threadIdx.x == 0) s_claim[claim_parity] = atomicAdd(counter, 1u);
+                    __syncthreads();
+                    kq = s_claim[claim_parity];
+                    claim_parity ^= 1u;
+                } else {
+                    if (lane == 0) kq = atomicAdd(counter, 1u);
+                }
                 kq = __builtin_amdgcn_readfirstlane(kq);
                 tile = n_waves + kq;
                 if (tile >= Q.n_tiles) tile = 0xffffffffu;
@@ -789,7 +802,7 @@ RM_DI void rm_stream_body(const RmParams &U, const S &sc) {
                             if (touch) c_hit++;
                             PixelOut po; po.oidx = oidx; po.depth = t; po.hit = touch ? 1u : 0u;
                             po.rgba = U.src ? (reinterpret_cast<const uint32_t *>(U.src)[gidx] | 0xFF000000u) : U.bg_rgba8;
-                            rm_store_pixel(U, po);
+                            if (writer) rm_store_pixel(U, po);
                             phase = RM_PH_IDLE;
                         }
                     } else {
@@ -798,7 +811,7 @@ RM_DI void rm_stream_body(const RmParams &U, const S &sc) {
                         PixelOut po; po.oidx = oidx; po.depth = length; po.hit = 1u;
                         po.rgba = rm_unorm8((base.x * shadow) * ao) | (rm_unorm8((base.y * shadow) * ao) << 8) |
                                   (rm_unorm8((base.z * shadow) * ao) << 16) | 0xFF000000u;
-                        rm_store_pixel(U, po);
+                        if (writer) rm_store_pixel(U, po);
                         phase = RM_PH_IDLE;
                     }
                 }
@@ -826,8 +839,10 @@ RM_DI void rm_stream_body(const RmParams &U, const S &sc) {
     }
 
     c_hit = rm_wave_sum(c_hit); c_p = rm_wave_sum(c_p); c_s = rm_wave_sum(c_s);
+    if (COOP && !writer) c_hit = c_p = c_s = 0;        // the four waves counted the same rays: one slot per wave, three of them empty
     if (lane == 0) {
-        unsigned *out = U.partials + RM_SLOT_WORDS * gw;
+        const unsigned slot = COOP ? blockIdx.x * 4u + (threadIdx.x >> 6) : gw;
+        unsigned *out = U.partials + RM_SLOT_WORDS * slot;
         out[0] = c_hit; out[1] = c_p; out[2] = c_s;
 #ifdef RM_TIMELINE
         out[3] = out[4] = out[5] = out[6] = out[7] = 0;

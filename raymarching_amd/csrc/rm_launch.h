@@ -38,6 +38,9 @@ int rm_variant_index(const RmParams &U);
 
 // persistent kernel with lane-level ray compaction; same calling convention as rm_launch_queue
 hipError_t rm_launch_stream(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu);
+// true if rm_launch_stream runs U with one workgroup (not one wave) per tile: big tables staged whole in LDS, whose
+// evaluations the four waves of a workgroup share
+bool rm_stream_is_coop(const RmParams &U);
 
 // the persistent kernel with the march loops on the fast (tolerance, not bit-exact) distance evaluation; 4-slot scenes
 // only; same calling convention as rm_launch_queue

@@ -40,3 +40,12 @@ a_ms, a_st, a = run(1, 256, w, h)
 b_ms, b_st, b = run(0, 256, w, h)
 same = all(np.array_equal(x, y) for x, y in zip(a, b)) and a_st == b_st
 print(f"stress256 1080p: tile {a_ms:.2f} ms, coop (auto) {b_ms:.2f} ms, {a_ms / b_ms:.2f}x, identical {same}  {b_st}", flush=True)
+c_ms, c_st, c = run(3, 256, w, h)
+same = all(np.array_equal(x, y) for x, y in zip(a, c)) and a_st == c_st
+print(f"stress256 1080p: stream kernel with shared evaluations {c_ms:.2f} ms, {a_ms / c_ms:.2f}x the one-wave tile kernel, identical {same}", flush=True)
+for n in (33, 100, 257):
+    a_ms, a_st, a = run(1, n, 333, 187, reps=1)
+    c_ms, c_st, c = run(3, n, 333, 187, reps=1)
+    same = all(np.array_equal(x, y) for x, y in zip(a, c)) and a_st == c_st
+    print(f"n = {n}: tile {a_ms:.2f} ms, stream-coop {c_ms:.2f} ms, identical {same}", flush=True)
+    assert same, n
