@@ -261,6 +261,67 @@ def test_pose_batch_equals_single_blits(oracle, torch_cuda):
     assert np.array_equal(c[2].cpu().numpy(), ref["rgba"])
 
 
+@pytest.mark.parametrize("kernel", ["auto", "tile", "stream"])
+def test_table_scene_in_bands_and_pose_batches(torch_cuda, kernel):
+    """a 100-primitive table (the kernels whose four waves share a tile, or one wave per tile) rendered as interleaved row
+    bands and as a batch of three poses equals the one-call frames of the same context bit for bit, counters included"""
+    torch = torch_cuda
+    from raymarching_amd import Material, Raymarching, RenderTexture, scenes
+    from raymarching_amd.material import _fp, _ptr, current_stream_handle
+    w, h, band, parts = 203, 117, 5, 3
+    dev = "cuda:0"
+    with Material() as mat:
+        mat.set_kernel(KERNELS.get(kernel, 0))
+        for k_, v_ in scenes.STRESS_FLOATS.items():
+            mat.SetFloat(k_, v_)
+        mat.SetFloat("_MaxSteps", 96.0)
+        mat.SetVector("_WorldSpaceLightPos0", scenes.WORLD_SPACE_LIGHT_POS0)
+        mat.SetPrimitives(scenes.stress_primitives(100, seed=0x5EED0064))
+        singles, fcs, c2ws, pos, stats = [], [], [], [], []
+        for k in (3, 20, 41):
+            rm = Raymarching(scenes.orbit_camera(k, 64, w, h), mat, scenes.default_transforms())
+            rt = RenderTexture(w, h, device=dev)
+            rm.OnRenderImage(None, rt)
+            stats.append(mat.stats())
+            singles.append(rt)
+            fcs.append(rm.GetFrustumCorners().m); c2ws.append(rm.cam.cameraToWorldMatrix.m); pos.append(rm.cam.transform.position)
+        assert stats[0]["n_hit"] > 0
+        n = len(singles)
+        c = torch.zeros((n, h, w, 4), dtype=torch.uint8, device=dev)
+        d = torch.zeros((n, h, w), dtype=torch.float32, device=dev)
+        m = torch.zeros((n, h, w), dtype=torch.uint8, device=dev)
+        arr = [np.ascontiguousarray(np.stack(a), dtype=np.float32) for a in (fcs, c2ws, pos)]
+        mat._ck(mat._lib.rm_blit_poses_device(mat.handle, n, _fp(arr[0]), _fp(arr[1]), _fp(arr[2]), _ptr(c), _ptr(d), _ptr(m), w, h,
+                                              current_stream_handle(dev)))
+        st = mat.stats()
+        torch.cuda.synchronize()
+        for key in ("n_hit", "sum_steps_p", "sum_steps_s", "n_pixels"):
+            assert st[key] == sum(s_[key] for s_ in stats), key
+        for i in range(n):
+            assert torch.equal(c[i], singles[i].color) and torch.equal(m[i], singles[i].hit)
+            assert torch.equal(d[i].view(torch.int32), singles[i].depth.view(torch.int32))
+        # the last pose again, as row bands (the camera properties are still that pose's)
+        ys = torch.arange(h, device=dev)
+        out_c, out_d, out_h = torch.zeros_like(singles[-1].color), torch.zeros_like(singles[-1].depth), torch.zeros_like(singles[-1].hit)
+        tot = {"n_hit": 0, "sum_steps_p": 0, "sum_steps_s": 0, "n_pixels": 0}
+        for p_ in range(parts):
+            rows = mat._lib.rm_band_rows(h, band, p_, parts)
+            cb = torch.zeros((rows, w, 4), dtype=torch.uint8, device=dev)
+            db = torch.zeros((rows, w), dtype=torch.float32, device=dev)
+            mb = torch.zeros((rows, w), dtype=torch.uint8, device=dev)
+            mat._ck(mat._lib.rm_blit_bands_device(mat.handle, None, None, _ptr(cb), _ptr(db), _ptr(mb), w, h, band, p_, parts,
+                                                  current_stream_handle(dev)))
+            sb = mat.stats()
+            for key in tot:
+                tot[key] += sb[key]
+            sel = ((ys // band) % parts) == p_
+            out_c[sel], out_d[sel], out_h[sel] = cb, db, mb
+        torch.cuda.synchronize()
+        assert torch.equal(out_c, singles[-1].color) and torch.equal(out_h, singles[-1].hit)
+        assert torch.equal(out_d.view(torch.int32), singles[-1].depth.view(torch.int32))
+        assert tot == {key: stats[-1][key] for key in tot}
+
+
 def test_pose_batch_at_full_size(torch_cuda):
     """three 7680x4320 orbit poses in one rm_blit_poses_device call; the middle one is pose 17, whose
     hashes are committed"""
