@@ -481,7 +481,11 @@ def run_multi(args) -> None:
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
-    counts_group = dist.new_group(backend="gloo")               # record counts travel as host tensors
+    try:
+        counts_group = dist.new_group(backend="gloo")           # record counts travel as host tensors
+    except Exception as e:                                      # no host-side transport on this node: RCCL carries them too
+        print(f"bench.py: no gloo group ({e}); record counts go over RCCL", file=sys.stderr, flush=True)
+        counts_group = None
 
     from raymarching_amd import Material, Raymarching, ShadowMapDirectional, scenes
     from raymarching_amd.distributed import DenseFrames, TileGather, poses_of, render_frame_bands

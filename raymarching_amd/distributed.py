@@ -181,7 +181,8 @@ class TileGather:
     """Gathers finished frames to the root as compact tile records (rm_compact_frames_device): only the 8x8
     tiles that hold a hit pixel travel, everything else the root reconstructs from the background it already
     has (rm_expand_frames_device).  Record counts differ per rank and per batch, so the exchange is one small
-    count all-gather on `count_group` (host tensors: gloo) followed by point-to-point transfers of exactly
+    count all-gather on `count_group` (host tensors over gloo; device tensors if that group is RCCL too) followed by
+    point-to-point transfers of exactly
     count records from every peer to the root (`group`: RCCL over xGMI on GPUs, each peer on its own link).
 
         g = TileGather(compact, capacity_records, like_device, root=0)
@@ -234,8 +235,15 @@ class TileGather:
         if t.count_ready is not None:
             t.count_ready.synchronize()
         mine = int(t.count_host.item())
-        counts = [torch.zeros(1, dtype=torch.int32) for _ in range(self.world)]
-        if self.world > 1:
+        if self.world > 1 and self.cuda and dist.get_backend(self.count_group) == "nccl":
+            # no host-side group: the counts travel as device tensors, on the side stream so that they do not queue
+            # behind rendering that is already enqueued on the current one
+            with torch.cuda.stream(self.side):
+                outs = [torch.zeros(1, dtype=torch.int32, device=self.device) for _ in range(self.world)]
+                dist.all_gather(outs, torch.tensor([mine], dtype=torch.int32, device=self.device), group=self.count_group)
+                counts = [int(c) for c in torch.cat(outs).tolist()]
+        elif self.world > 1:
+            counts = [torch.zeros(1, dtype=torch.int32) for _ in range(self.world)]
             dist.all_gather(counts, torch.tensor([mine], dtype=torch.int32), group=self.count_group)
             counts = [int(c.item()) for c in counts]
         else:

@@ -130,6 +130,23 @@ def test_error_codes_without_gpu_calls():
         assert lib.rm_set_primitives(m.handle, prim, 1) == native.RM_E_ARG
         assert lib.rm_set_primitives(m.handle, prim, native.RM_MAX_PRIMS + 1) == native.RM_E_RANGE
         assert lib.rm_set_kernel(m.handle, 99) == native.RM_E_ARG
+        for k in range(6):                                   # 0 automatic, 1..3 and 5 exact kernels, 4 the tolerance kernels
+            assert lib.rm_set_kernel(m.handle, k) == native.RM_OK
+        assert lib.rm_set_kernel(m.handle, 6) == native.RM_E_ARG and lib.rm_set_kernel(m.handle, -1) == native.RM_E_ARG
+        # the transport entry points check their arguments before they touch the GPU
+        buf = C.create_string_buffer(256)
+        p = C.cast(buf, C.c_void_p)
+        assert lib.rm_compact_frames_device(m.handle, None, p, 8, 8, 1, p, p, None) == native.RM_E_ARG
+        assert lib.rm_compact_frames_device(m.handle, p, p, 8, 8, 0, p, p, None) == native.RM_E_ARG
+        assert lib.rm_expand_frames_device(m.handle, None, 3, None, p, 8, 8, 1, None) == native.RM_E_ARG      # records missing
+        assert lib.rm_expand_frames_device(m.handle, p, 1, None, None, 8, 8, 1, None) == native.RM_E_ARG      # no destination
+        assert lib.rm_update_frames_device(m.handle, None, 2, p, 1, None, p, 8, 8, 1, None) == native.RM_E_ARG
+        assert lib.rm_update_frames_device(m.handle, p, 1, None, 2, None, p, 8, 8, 1, None) == native.RM_E_ARG
+        assert lib.rm_update_frames_device(m.handle, p, 1, p, 1, None, p, 0, 8, 1, None) == native.RM_E_ARG
+        assert lib.rm_update_frames_device(m.handle, p, 1, p, 1, None, p, 40000, 8, 1, None) == native.RM_E_RANGE
+        odd = C.c_void_p(p.value + 1)
+        assert lib.rm_update_frames_device(m.handle, p, 1, p, 1, None, odd, 8, 8, 1, None) == native.RM_E_ARG  # alignment
+        assert lib.rm_tile_record_bytes() == 196
         st = native.RmStats()
         assert lib.rm_get_stats(m.handle, C.byref(st)) == native.RM_E_ARG       # nothing rendered yet
     assert lib.rm_set_float(None, b"x", 1.0) == native.RM_E_ARG
