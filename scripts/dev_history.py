@@ -1,0 +1,59 @@
+"""Developer tool: what the tile-queue ordering is worth at 3840x2160 with a moving camera.  16 orbit poses; per frame time
+with (a) each pose repeated (the previous frame's costs predict this frame exactly), (b) the poses in turn (stale
+prediction), (c) ordering by the previous frame switched off."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import bench
+from raymarching_amd import Material, Raymarching, scenes
+from raymarching_amd.material import _fp, _ptr, current_stream_handle
+
+w, h = int(os.environ.get("RM_W", "3840")), int(os.environ.get("RM_H", "2160"))
+dev = "cuda:0"
+mat = Material(device=0)
+Raymarching(scenes.default_camera(w, h), mat, scenes.default_transforms()).bind()
+mat.SetVector("_WorldSpaceLightPos0", scenes.WORLD_SPACE_LIGHT_POS0)
+lib, ctx = mat._lib, mat.handle
+fr = bench.Frame(torch, dev, w, h)
+stream = current_stream_handle(dev)
+n_orbit = 16
+arr = [bench.pose_arrays(scenes, Raymarching, mat, [k * (bench.N_POSES // n_orbit)], w, h) for k in range(n_orbit)]
+pos4 = [np.ascontiguousarray(np.append(a[2][0], 0.0), dtype=np.float32) for a in arr]
+
+
+def set_pose(i):
+    fcs, c2ws, _ = arr[i]
+    lib.rm_set_matrix(ctx, b"_FrustrumCorners", _fp(fcs[0]))
+    lib.rm_set_matrix(ctx, b"_CameraInvViewMatrix", _fp(c2ws[0]))
+    lib.rm_set_vector(ctx, b"_WorldSpaceCameraPos", _fp(pos4[i]))
+
+
+def blit():
+    mat._ck(lib.rm_blit_device(ctx, None, None, _ptr(fr.color), _ptr(fr.depth), _ptr(fr.hit), w, h, stream))
+
+
+def timed(fn, n):
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(n):
+        fn(i)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+reps = 20
+tot = 0.0
+for i in range(n_orbit):
+    set_pose(i)
+    blit(); blit()
+    tot += timed(lambda _i: blit(), reps)
+print(f"(a) each pose repeated, exact prediction: {tot / n_orbit:.1f} us per frame", flush=True)
+for i in range(n_orbit):
+    set_pose(i); blit()
+t = timed(lambda i: (set_pose(i % n_orbit), blit()), n_orbit * 4)
+print(f"(b) poses in turn, stale prediction:      {t:.1f} us per frame", flush=True)
+mat.SetFloat("_RmTileFeedback", 0.0)
+t = timed(lambda i: (set_pose(i % n_orbit), blit()), n_orbit * 4)
+print(f"(c) poses in turn, no ordering:           {t:.1f} us per frame", flush=True)
