@@ -9,11 +9,6 @@ __global__ RM_QLB void rm_queue_kernel4(const RmParams U) {
     rm_queue_body(U, sc);
 }
 
-__global__ __launch_bounds__(256, RM_Q_MIN_WAVES_ROT) void rm_queue_kernelF(const RmParams U) {
-    SceneF sc(U);
-    rm_queue_body(U, sc);
-}
-
 // the table walk keeps four primitives' records in flight: 2 waves per SIMD (<= 256 VGPRs) avoids spills
 template <bool ROT, int SCL>
 __global__ __launch_bounds__(256, RM_Q_MIN_WAVES_ROT) void rm_queue_kernelN(const RmParams U) {
@@ -48,16 +43,6 @@ hipError_t launch_queue_variant(const RmParams &U, unsigned blocks, hipStream_t 
 }  // namespace
 
 hipError_t rm_launch_queue(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu) {
-    if (U.body != RM_BODY_PRIMS) {
-        const size_t lds = (size_t)U.queue.bitmap_words * 4;
-        if (blocks_per_cu) {
-            int n = 0;
-            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rm_queue_kernelF, 256, lds);
-            blocks_per_cu[0] = blocks_per_cu[1] = n;
-            return e;
-        }
-        hipLaunchKernelGGL(rm_queue_kernelF, dim3(blocks), dim3(256), lds, stream, U);
-        return hipGetLastError();
-    }
+    if (U.body != RM_BODY_PRIMS) return rm_launch_queue_body(U, blocks, stream, blocks_per_cu);
     RM_DISPATCH_VARIANT(launch_queue_variant, U, U, blocks, stream, blocks_per_cu);
 }

@@ -1,4 +1,4 @@
-// rm_k_tile.hip -- one launch block per image tile: the reference scene, table scenes, fractal bodies;
+// rm_k_tile.hip -- one launch block per image tile: the reference scene, table scenes;
 // counter reduction.
 #include "rm_kernels_common.h"
 
@@ -68,11 +68,6 @@ __global__ RM_LB void rm_tile_kernelN(const RmParams U) {
     }
 }
 
-// fractal scene() bodies: one kernel each, the slot-0 transform is specialised by wave-uniform branches
-__global__ RM_LB void rm_tile_kernelF(const RmParams U) {
-    SceneF sc(U);
-    rm_pixel(U, sc);
-}
 template <bool ROT, int SCL>
 hipError_t launch_variant(const RmParams &U, dim3 grid, hipStream_t stream) {
     if (U.n_prims > 0) hipLaunchKernelGGL((rm_tile_kernelN<ROT, SCL>), grid, dim3(RM_BLOCK), (size_t)U.lds_prims * sizeof(RmPrimDev), stream, U);
@@ -110,9 +105,6 @@ hipError_t rm_launch_tiles(const RmParams &U, hipStream_t stream) {
     dim3 grid((unsigned)((U.w + 8 * RM_BWX - 1) / (8 * RM_BWX)), (unsigned)((U.rows + 8 * RM_BWY - 1) / (8 * RM_BWY)), (unsigned)U.n_poses);
     if (grid.y > 65535u || grid.z > 65535u) return hipErrorInvalidValue;
     if (U.fx_flags != 0 || U.fx_view != 0 || U.light_model != 0 || U.dom_op != RM_DOM_NONE || (U.mode == RM_MODE_FRAG && U.shadow_mode != 0)) return rm_launch_tiles_fx(U, grid.x, grid.y, grid.z, stream);
-    if (U.body != RM_BODY_PRIMS) {
-        hipLaunchKernelGGL(rm_tile_kernelF, grid, dim3(RM_BLOCK), 0, stream, U);
-        return hipGetLastError();
-    }
+    if (U.body != RM_BODY_PRIMS) return rm_launch_tiles_body(U, grid.x, grid.y, grid.z, stream);
     RM_DISPATCH_VARIANT(launch_variant, U, U, grid, stream);
 }

@@ -11,6 +11,11 @@ hipError_t rm_launch_tiles(const RmParams &U, hipStream_t stream);
 // the same with frag's optional lines (U.fx_flags / U.fx_view); called by rm_launch_tiles with its grid
 hipError_t rm_launch_tiles_fx(const RmParams &U, unsigned grid_x, unsigned grid_y, unsigned grid_z, hipStream_t stream);
 
+// the same two launchers for the scene() bodies other than the primitives (U.body != RM_BODY_PRIMS); called by rm_launch_tiles
+// and rm_launch_queue
+hipError_t rm_launch_tiles_body(const RmParams &U, unsigned grid_x, unsigned grid_y, unsigned grid_z, hipStream_t stream);
+hipError_t rm_launch_queue_body(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu);
+
 // 32-bit words per counter slot
 unsigned rm_slot_words();
 // number of blocks (= counter slots) rm_launch_tiles uses for a launch of this shape
