@@ -262,6 +262,9 @@ template <> struct PrimTable<true> {
         union { RmPrimDev p; rm_u4 v[sizeof(RmPrimDev) / 16]; } u;
 #pragma unroll
         for (int j = 0; j < (int)(sizeof(RmPrimDev) / 16); j++) u.v[j] = T[i * (int)(sizeof(RmPrimDev) / 16) + j];   // ds_read_b128, same address in every lane
+        // every lane holds the same record: say so for the word that steers the control flow, so that the choice of the
+        // primitive's code is a scalar branch instead of three vector compares with their exec-mask bookkeeping
+        u.p.type = __builtin_amdgcn_readfirstlane(u.p.type);
         return u.p;
     }
 };
