@@ -69,7 +69,9 @@ struct SceneNCoop {
 // the scene object of the calling wave: xw = 2 * 4 * 64 floats, x4 = 4 * 4 * 64 floats of this workgroup's LDS
 template <bool ROT, int SCL, bool CSG>
 RM_DI SceneNCoop<ROT, SCL> rm_make_coop_scene(const RmParams &U, PrimTable<true> t, RM_LDS float *xw, RM_LDS float *x4) {
-    const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    // the wave index is the same in every lane: as a scalar, the chunk bounds and with them the whole table walk stay on
+    // the scalar unit (left as a vector value, the walk becomes a divergent loop with exec-mask bookkeeping)
+    const unsigned lane = threadIdx.x & 63u, wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // chunk = pow2ceil(n) / 4, n >= 8
     const int chunk = (1 << (32 - __builtin_clz((unsigned)U.n_prims - 1u))) >> 2;
     const int lo = (int)wv * chunk;

@@ -11,9 +11,9 @@
 namespace {
 
 // CSG: the table carries op bits.  Kept apart so that the plain-union kernel, which is the one the big tables of the
-// benchmark use, does not carry the smax paths in its register budget (4 waves per SIMD; 3 with op bits).
+// benchmark use, does not carry the smax paths in its register budget (both fit 4 waves per SIMD).
 template <bool ROT, int SCL, bool CSG>
-__global__ __launch_bounds__(256, CSG ? 3 : 4) void rm_coop_kernelN(const RmParams U) {
+__global__ __launch_bounds__(256, 4) void rm_coop_kernelN(const RmParams U) {
     __shared__ float s_xw[2 * 4 * 64];
     __shared__ float s_x4[4 * 4 * 64];
     PrimTable<true> t;

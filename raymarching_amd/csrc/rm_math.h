@@ -339,7 +339,7 @@ struct SceneN {
             for (int l = 0; l < RM_ITEM_LEVELS - 1; l++)
                 if (l < merges) v = comb<CSG>(st[l], v, (CSG && ((tw >> (RM_CASCADE_SHIFT + l)) & 1)) ? -1.0f : 1.0f);
 #pragma unroll
-            for (int l = 0; l < RM_ITEM_LEVELS; l++) if (l == merges) st[l] = v;
+            for (int l = 0; l < RM_ITEM_LEVELS; l++) if (l == merges) st[l] = v;       // (a switch on the uniform `merges` was measured: slower)
         }
         int items = groups;
         T acc = T();
