@@ -101,29 +101,31 @@ struct PixelOut { uint32_t rgba; float depth; uint32_t hit; size_t oidx; uint32_
 // `sv`: optional copy of U.view in LDS (ro, bl, br, tl, tr as in RmView).  The persistent kernel reads the
 // view from there once per tile: held in scalar registers across the whole tile loop, these 15 values
 // (with everything else that loop keeps) overflow the SGPR file and come back as v_readlane traffic.
+template <int SHAPE = 0>
 RM_DI void rm_setup_ray(const RmParams &U, int x, int yl, int pose, V3 &ro, V3 &rd, float &depth, size_t &gidx, size_t &oidx,
                         rm_lds_cfloat sv = nullptr, bool use_sv = false) {
+    constexpr bool PLAIN = SHAPE != 0;
     // compact local row -> frame row (row-band shard; identity when n_parts == 1)
     int y = yl;
-    if (U.n_parts != 1) {
+    if (!PLAIN && U.n_parts != 1) {
         const int band = yl / U.band_rows;
         y = (band * U.n_parts + U.part) * U.band_rows + (yl - band * U.band_rows);
     }
     gidx = (size_t)y * (size_t)U.w + (size_t)x;
     oidx = ((size_t)pose * (size_t)U.rows + (size_t)yl) * (size_t)U.w + (size_t)x;
 
-    const RmView &V = U.views ? U.views[pose] : U.view;
+    const RmView &V = (SHAPE == 2 || (!PLAIN && U.views)) ? U.views[pose] : U.view;
     // pixel centre / frame size; the host has checked for this frame size that the 3-op exact division
     // by a uniform divisor gives the IEEE quotient for every column and row, else inv_w = 0
     float uu, vv;
-    if (U.inv_w != 0.0f) {
+    if (PLAIN || U.inv_w != 0.0f) {
         uu = rm_div_by((float)x + 0.5f, (float)U.w, U.inv_w);
         vv = rm_div_by((float)y + 0.5f, (float)U.h, U.inv_h);
     } else {
         uu = ((float)x + 0.5f) / (float)U.w;
         vv = ((float)y + 0.5f) / (float)U.h;
     }
-    if (U.mode == RM_MODE_DEPTH_ORTHO) {
+    if (!PLAIN && U.mode == RM_MODE_DEPTH_ORTHO) {
         V3 c0 = mk3(U.ortho_c[0][0], U.ortho_c[0][1], U.ortho_c[0][2]);
         V3 c1 = mk3(U.ortho_c[1][0], U.ortho_c[1][1], U.ortho_c[1][2]);
         V3 c2 = mk3(U.ortho_c[2][0], U.ortho_c[2][1], U.ortho_c[2][2]);
@@ -132,7 +134,7 @@ RM_DI void rm_setup_ray(const RmParams &U, int x, int yl, int pose, V3 &ro, V3 &
         rd = mk3(U.ortho_fwd[0], U.ortho_fwd[1], U.ortho_fwd[2]);
     } else {
         // rasteriser interpolation of vert's viewDir (cginc:26-33) to the pixel centre
-        if (use_sv) {
+        if (SHAPE == 1 || (!PLAIN && use_sv)) {
             typedef float rm_f4 __attribute__((ext_vector_type(4)));
             const volatile RM_LDS rm_f4 *q = (const volatile RM_LDS rm_f4 *)sv;      // four ds_read_b128, one wait
             const rm_f4 a = q[0], b = q[1], c = q[2], d = q[3];
@@ -148,7 +150,7 @@ RM_DI void rm_setup_ray(const RmParams &U, int x, int yl, int pose, V3 &ro, V3 &
         }
     }
     depth = U.far_plane;                                          // shader:154
-    if (U.mode == RM_MODE_FRAG && U.sdepth) depth = U.sdepth[gidx];
+    if (!PLAIN && U.mode == RM_MODE_FRAG && U.sdepth) depth = U.sdepth[gidx];
     depth = fminf(depth, U.max_dist);                             // cginc:368
 }
 
@@ -165,7 +167,8 @@ RM_DI PixelOut rm_compute_pixel(const RmParams &U, const S &sc, int x, int yl, i
     V3 ro, rd;
     float depth;
     size_t gidx;
-    rm_setup_ray(U, x, yl, pose, ro, rd, depth, gidx, out.oidx, sv, use_sv);
+    constexpr bool PLAIN = rm_shape<S>::value != 0;
+    rm_setup_ray<rm_shape<S>::value>(U, x, yl, pose, ro, rd, depth, gidx, out.oidx, sv, use_sv);
 
     const float sf = rm_vgpr(U.step_factor);
     MarchResult r = rm_raymarch(sc, ro, rd, depth, U.n_steps, sf);
@@ -176,7 +179,7 @@ RM_DI PixelOut rm_compute_pixel(const RmParams &U, const S &sc, int x, int yl, i
     out.rgba = 0;
     out.steps = 0;
 
-    if (U.mode == RM_MODE_FRAG) {
+    if (PLAIN || U.mode == RM_MODE_FRAG) {
         if (r.hit) {
             const V3 L = mk3(rm_vgpr(U.light[0]), rm_vgpr(U.light[1]), rm_vgpr(U.light[2]));
             V3 hp = mk3(ro.x + rd.x * r.length, ro.y + rd.y * r.length, ro.z + rd.z * r.length);   // shader:174
@@ -202,7 +205,7 @@ RM_DI PixelOut rm_compute_pixel(const RmParams &U, const S &sc, int x, int yl, i
             float cg = ((s.y * ndl) * shadow) * ao;
             float cb = ((s.z * ndl) * shadow) * ao;
             out.rgba = rm_unorm8(cr) | (rm_unorm8(cg) << 8) | (rm_unorm8(cb) << 16) | 0xFF000000u;
-        } else if (U.src) {
+        } else if (!PLAIN && U.src) {
             out.rgba = reinterpret_cast<const uint32_t *>(U.src)[gidx] | 0xFF000000u;
         } else {
             out.rgba = U.bg_rgba8;
@@ -371,10 +374,11 @@ RM_DI PixelOut rm_compute_pixel_fx(const RmParams &U, const S &sc, int x, int yl
 
 // one dword of colour, one of depth and one byte of mask per pixel; a wave writes an 8x8 tile
 // as eight 32-byte row segments per plane
+template <bool PLAIN = false>
 RM_DI void rm_store_pixel(const RmParams &U, const PixelOut &o) {
-    if (U.mode == RM_MODE_FRAG && U.dst_rgba) reinterpret_cast<uint32_t *>(U.dst_rgba)[o.oidx] = o.rgba;
-    if (U.dst_depth) U.dst_depth[o.oidx] = o.depth;
-    if (U.dst_hit) U.dst_hit[o.oidx] = (uint8_t)o.hit;
+    if (PLAIN || (U.mode == RM_MODE_FRAG && U.dst_rgba)) reinterpret_cast<uint32_t *>(U.dst_rgba)[o.oidx] = o.rgba;
+    if (PLAIN || U.dst_depth) U.dst_depth[o.oidx] = o.depth;
+    if (PLAIN || U.dst_hit) U.dst_hit[o.oidx] = (uint8_t)o.hit;
 }
 // the optional per-pixel step-count plane (the reference's nearest thing is the commented-out heat map, shader:203)
 RM_DI void rm_store_steps(const RmParams &U, const PixelOut &o) {
@@ -517,7 +521,9 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
         s_view[threadIdx.x] = v[threadIdx.x];
     }
     rm_lds_cfloat sv = (rm_lds_cfloat)s_view;
-    const bool use_sv = U.views == nullptr;
+    constexpr int SHAPE = rm_shape<S>::value;
+    constexpr bool PLAIN = SHAPE != 0;
+    const bool use_sv = SHAPE == 1 || (!PLAIN && U.views == nullptr);
     // this frame's heavy bitmap -> LDS
     if (Q.use_history) {
         const unsigned *bitmap_cur = Q.bitmaps + (size_t)Q.hv_cur * Q.bitmap_words;
@@ -600,7 +606,7 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
             // its wave gets issue priority over waves rendering cheap tiles on the same SIMD
             if (cur < n_heavy) __builtin_amdgcn_s_setprio(RM_HEAVY_PRIO); else __builtin_amdgcn_s_setprio(0);
             unsigned pose = 0, t2 = tile;
-            if (U.n_poses != 1) {
+            if (SHAPE == 2 || (!PLAIN && U.n_poses != 1)) {
                 const unsigned per_pose = Q.tiles_x * Q.tiles_y;
                 pose = tile / per_pose; t2 = tile - pose * per_pose;
             }
@@ -633,7 +639,7 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
         }
         // 4. framebuffer stores of `cur`, and its cost for the next frame's ordering
         if (tile != 0xffffffffu) {
-            if (have) rm_store_pixel(U, po);
+            if (have) rm_store_pixel<PLAIN>(U, po);
             // this lane's scene evaluations; the wave maximum is the tile's length
             const unsigned cost = rm_wave_max(t_p + t_s + (t_hit ? 7u : 0u));
 #ifdef RM_TIMELINE

@@ -80,6 +80,11 @@ RM_DI V3 rm_normalize(V3 a) { float r = 1.0f / sqrtf(rm_dot3(a, a)); return mk3(
 // Scene classes whose march loops may round differently from a strict binary32 evaluation (the opt-in tolerance
 // kernel, rm_fast.h) say so here; the loops then fuse their own multiply-adds too.
 template <class S> struct rm_is_fast { static constexpr bool value = false; };
+// A scene type can promise a plain launch shape: fragment pass, whole frames, no source image, no depth texture, all three
+// output planes, frame size with exact reciprocals -- either one frame with the view in the kernel arguments (1) or a
+// batch of poses with the views in device memory (2).  The per-tile code then drops the uniform branches (and the scalar
+// registers their conditions occupy) that the other launch shapes need.  0 = any shape.
+template <class S> struct rm_shape { static constexpr int value = 0; };
 
 // scale handling chosen per scene on the host
 enum { RM_SCL_UNIT = 0, RM_SCL_RCP = 1, RM_SCL_DIV = 2 };
@@ -243,6 +248,12 @@ struct Scene4 {
         return rm_smin4(rm_smin4(o[0], o[1]), rm_smin4(o[2], o[3]));
     }
 };
+
+template <bool ROT, int SCL, int SHAPE>
+struct Scene4Plain : Scene4<ROT, SCL> {
+    RM_DI explicit Scene4Plain(const RmParams &u) : Scene4<ROT, SCL>(u) {}
+};
+template <bool ROT, int SCL, int SHAPE> struct rm_shape<Scene4Plain<ROT, SCL, SHAPE>> { static constexpr int value = SHAPE; };
 
 // N-primitive scene from a table in global memory.  Every lane walks the table
 // with the same index, so the loads are wave-uniform and go through the scalar
