@@ -642,7 +642,7 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, int family, WorkMem
         return fail(c, RM_E_RANGE, "the persistent kernel's tile bitmap and primitive table do not fit one workgroup's LDS for this frame");
     }
     const int vi = rm_variant_index(P), tab = P.n_prims > 0 ? 1 : 0;
-    const uint64_t occ_key = ((uint64_t)(streamk ? 1 : fast ? 2 : 3 + rm_queue_shape(P)) << 60) | ((uint64_t)vi << 52) | ((uint64_t)tab << 48) | (uint64_t)lds_bytes;
+    const uint64_t occ_key = ((uint64_t)(streamk ? 1 : (fast ? 8 : 4) + rm_queue_shape(P)) << 60) | ((uint64_t)vi << 52) | ((uint64_t)tab << 48) | (uint64_t)lds_bytes;
     auto occ_it = c->occ.find(occ_key);
     if (occ_it == c->occ.end()) {
         int o[2] = {0, 0};

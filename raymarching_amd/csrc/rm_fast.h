@@ -74,7 +74,7 @@ RM_DI float smin_w(float a, float b) {
 // The reference's four slots with the march-loop evaluation on the fast path; everything else (w for the normal
 // taps, full for the colour) is the strict Scene4's.  SCL is RM_SCL_UNIT or RM_SCL_RCP (the host maps scenes that
 // need a true division to RM_SCL_RCP here: the reciprocals are always at hand).
-template <bool ROT, int SCL>
+template <bool ROT, int SCL, int SHAPE = 0>
 struct Scene4Fast : Scene4<ROT, SCL> {
     RM_DI explicit Scene4Fast(const RmParams &u) : Scene4<ROT, SCL>(u) {}
     RM_DI float wm(V3 p) const {
@@ -89,4 +89,5 @@ struct Scene4Fast : Scene4<ROT, SCL> {
 }  // namespace rmf
 #pragma clang fp contract(off)
 
-template <bool ROT, int SCL> struct rm_is_fast<rmf::Scene4Fast<ROT, SCL>> { static constexpr bool value = true; };
+template <bool ROT, int SCL, int SHAPE> struct rm_is_fast<rmf::Scene4Fast<ROT, SCL, SHAPE>> { static constexpr bool value = true; };
+template <bool ROT, int SCL, int SHAPE> struct rm_shape<rmf::Scene4Fast<ROT, SCL, SHAPE>> { static constexpr int value = SHAPE; };

@@ -51,23 +51,32 @@ hipError_t launch_cull_variant(const RmParams &U, dim3 grid, hipStream_t stream)
     return hipGetLastError();
 }
 
-template <bool ROT, int SCL>
+// SHAPE: the launch shape promised at compile time (rm_queue_shape): 0 any, 1 the plain frame, 2 a plain pose batch
+template <bool ROT, int SCL, int SHAPE>
 __global__ RM_QLB void rm_queue_kernel4_fast(const RmParams U) {
-    rmf::Scene4Fast<ROT, SCL> sc(U);
+    rmf::Scene4Fast<ROT, SCL, SHAPE> sc(U);
     rm_queue_body(U, sc);
+}
+
+template <bool ROT, int SCL, int SHAPE>
+hipError_t launch_fast_shape(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu) {
+    const size_t lds = (size_t)((U.queue.bitmap_words + 3u) & ~3u) * 4;
+    if (blocks_per_cu) {
+        int n = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rm_queue_kernel4_fast<ROT, SCL, SHAPE>, 256, lds);
+        blocks_per_cu[0] = blocks_per_cu[1] = n;
+        return e;
+    }
+    hipLaunchKernelGGL((rm_queue_kernel4_fast<ROT, SCL, SHAPE>), dim3(blocks), dim3(256), lds, stream, U);
+    return hipGetLastError();
 }
 
 template <bool ROT, int SCL>
 hipError_t launch_fast_variant(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu) {
-    const size_t lds = (size_t)((U.queue.bitmap_words + 3u) & ~3u) * 4;
-    if (blocks_per_cu) {
-        int n = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rm_queue_kernel4_fast<ROT, SCL>, 256, lds);
-        blocks_per_cu[0] = blocks_per_cu[1] = n;
-        return e;
-    }
-    hipLaunchKernelGGL((rm_queue_kernel4_fast<ROT, SCL>), dim3(blocks), dim3(256), lds, stream, U);
-    return hipGetLastError();
+    const int shape = rm_queue_shape(U);
+    if (shape == 1) return launch_fast_shape<ROT, SCL, 1>(U, blocks, stream, blocks_per_cu);
+    if (shape == 2) return launch_fast_shape<ROT, SCL, 2>(U, blocks, stream, blocks_per_cu);
+    return launch_fast_shape<ROT, SCL, 0>(U, blocks, stream, blocks_per_cu);
 }
 
 }  // namespace
