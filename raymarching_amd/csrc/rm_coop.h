@@ -72,7 +72,7 @@ RM_DI SceneNCoop<ROT, SCL> rm_make_coop_scene(const RmParams &U, PrimTable<true>
     // the wave index is the same in every lane: as a scalar, the chunk bounds and with them the whole table walk stay on
     // the scalar unit (left as a vector value, the walk becomes a divergent loop with exec-mask bookkeeping)
     const unsigned lane = threadIdx.x & 63u, wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // chunk = pow2ceil(n) / 4, n >= 8
+    // chunk = pow2ceil(n) / 4 >= 1 for n >= 3
     const int chunk = (1 << (32 - __builtin_clz((unsigned)U.n_prims - 1u))) >> 2;
     const int lo = (int)wv * chunk;
     int cnt = U.n_prims - lo;

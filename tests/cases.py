@@ -299,6 +299,9 @@ CASES = [
     Case("csg_random37_240x135", 240, 135, setup=_stress, prims=scenes.csg_random_primitives(37)),
     Case("csg_random70_160x90", 160, 90, setup=_stress, prims=scenes.csg_random_primitives(70, seed=0x5EED070)),
     # op bits in tables the cooperative kernel splits: 64 = four full chunks, 100 = 32, 32, 32, 4 (37 and 70 above: three chunks)
+    # the smallest tables that split over four waves: 3 = one primitive per wave and an idle one, 5 = chunks of 2, 2, 1
+    Case("csg_random3_96x54", 96, 54, setup=_stress, prims=scenes.csg_random_primitives(3, seed=0x5EED003)),
+    Case("csg_random5_96x54", 96, 54, setup=_stress, prims=scenes.csg_random_primitives(5, seed=0x5EED005)),
     Case("csg_random64_128x72", 128, 72, setup=_stress, prims=scenes.csg_random_primitives(64, seed=0x5EED064)),
     Case("csg_random100_128x72", 128, 72, setup=_stress, prims=scenes.csg_random_primitives(100, seed=0x5EED100)),
     Case("menger_closeup_320x180", 320, 180, setup=_fractal(1, True)),
