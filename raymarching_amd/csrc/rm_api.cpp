@@ -810,9 +810,10 @@ int launch(rm_ctx *c, const RmParams &U, hipStream_t stream, WorkMem M, bool rec
     if (kernel == RM_KERNEL_TILE) {
         const bool plain = U.fx_flags == 0 && U.fx_view == 0 && U.light_model == 0 && U.dom_op == RM_DOM_NONE && !U.dst_steps &&
                            !(U.mode == RM_MODE_FRAG && U.shadow_mode != 0);
-        // big tables: the four waves of a block share one 8x8 tile and split the table (same bits, waves that
-        // finish together, a four times shorter critical chain); rm_set_kernel(1) keeps the one-wave-per-tile kernel
-        const bool coop = plain && !cull && (c->kernel == RM_KERNEL_AUTO || c->kernel == RM_KERNEL_COOP) && U.body == RM_BODY_PRIMS &&
+        // tables: the four waves of a block share one 8x8 tile and split the table (same bits, waves that finish
+        // together, a four times shorter critical chain), with or without frag's optional lines; rm_set_kernel(1) keeps
+        // the one-wave-per-tile kernels
+        const bool coop = !(cull && plain) && c->kernel != RM_KERNEL_TILE && U.body == RM_BODY_PRIMS &&
                           U.n_prims >= RM_COOP_MIN_PRIMS && U.lds_prims == U.n_prims;
         unsigned n_blocks = coop ? rm_coop_blocks(U.w, U.rows, U.n_poses) : rm_tile_blocks(U.w, U.rows, U.n_poses);
         rc = ensure_partials(c, M, n_blocks);

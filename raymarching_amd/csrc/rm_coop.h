@@ -67,8 +67,9 @@ struct SceneNCoop {
 };
 
 // the scene object of the calling wave: xw = 2 * 4 * 64 floats, x4 = 4 * 4 * 64 floats of this workgroup's LDS
-template <bool ROT, int SCL, bool CSG>
-RM_DI SceneNCoop<ROT, SCL> rm_make_coop_scene(const RmParams &U, PrimTable<true> t, RM_LDS float *xw, RM_LDS float *x4) {
+// (csg: the table carries op bits; a compile-time constant at the call keeps the other tree out of the kernel)
+template <bool ROT, int SCL>
+RM_DI SceneNCoop<ROT, SCL> rm_make_coop_scene(const RmParams &U, PrimTable<true> t, RM_LDS float *xw, RM_LDS float *x4, bool csg) {
     // the wave index is the same in every lane: as a scalar, the chunk bounds and with them the whole table walk stay on
     // the scalar unit (left as a vector value, the walk becomes a divergent loop with exec-mask bookkeeping)
     const unsigned lane = threadIdx.x & 63u, wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -83,12 +84,12 @@ RM_DI SceneNCoop<ROT, SCL> rm_make_coop_scene(const RmParams &U, PrimTable<true>
     // U.tail_ops: below the chunk level the merges of the whole-table walk and of the chunk's walk are the same ones
     const int n_chunks = (U.n_prims + chunk - 1) / chunk;
     float o01 = 1.0f, o23 = 1.0f, otop = 1.0f;
-    if (CSG) {
+    if (csg) {
         o01 = t.get(chunk).osgn;
         otop = t.get(2 * chunk).osgn;
         if (n_chunks == 4) o23 = t.get(3 * chunk).osgn;
     }
-    return SceneNCoop<ROT, SCL>{SceneN<ROT, SCL, true>(tc, cnt, CSG, U.tail_ops), n_chunks, wv, lane, xw, x4, o01, o23, otop, 0u};
+    return SceneNCoop<ROT, SCL>{SceneN<ROT, SCL, true>(tc, cnt, csg, U.tail_ops), n_chunks, wv, lane, xw, x4, o01, o23, otop, 0u};
 }
 
 }  // namespace

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256, 4) void rm_coop_kernelN(const RmParams U) {
     t.T = rm_stage_table(U, 0);                                           // ends with a __syncthreads()
     const int tid = threadIdx.x;
     const unsigned lane = tid & 63, wv = tid >> 6;
-    const SceneNCoop<ROT, SCL> sc = rm_make_coop_scene<ROT, SCL, CSG>(U, t, (RM_LDS float *)s_xw, (RM_LDS float *)s_x4);
+    const SceneNCoop<ROT, SCL> sc = rm_make_coop_scene<ROT, SCL>(U, t, (RM_LDS float *)s_xw, (RM_LDS float *)s_x4, CSG);
     unsigned c_hit = 0, c_p = 0, c_s = 0;
     const int x = blockIdx.x * 8 + (int)(lane & 7u), yl = blockIdx.y * 8 + (int)(lane >> 3);
     if (x < U.w && yl < U.rows) {
@@ -34,10 +34,38 @@ __global__ __launch_bounds__(256, 4) void rm_coop_kernelN(const RmParams U) {
     }
 }
 
+// frag's optional lines, the light helpers, the shadow-map lookup, the domain operators and the step-count plane over a
+// table (rm_compute_pixel_fx): rarely the bottleneck of anything, so one instantiation serves tables with and without op bits
+template <bool ROT, int SCL>
+__global__ __launch_bounds__(256) void rm_coop_kernelN_fx(const RmParams U) {
+    __shared__ float s_xw[2 * 4 * 64];
+    __shared__ float s_x4[4 * 4 * 64];
+    PrimTable<true> t;
+    t.T = rm_stage_table(U, 0);
+    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const SceneNCoop<ROT, SCL> sc = rm_make_coop_scene<ROT, SCL>(U, t, (RM_LDS float *)s_xw, (RM_LDS float *)s_x4,
+                                                                   (U.scene_flags & RM_SF_CSG) != 0);
+    unsigned c_hit = 0, c_p = 0, c_s = 0;
+    const int x = blockIdx.x * 8 + (int)(lane & 7u), yl = blockIdx.y * 8 + (int)(lane >> 3);
+    if (x < U.w && yl < U.rows) {
+        PixelOut po = rm_compute_pixel_fx(U, SceneDom<SceneNCoop<ROT, SCL>>(sc, U), x, yl, (int)blockIdx.z, c_hit, c_p, c_s);
+        po.steps = c_p | (c_s << 16);          // this thread's only pixel: the counters are the pixel's own
+        if (wv == 0) { rm_store_pixel(U, po); rm_store_steps(U, po); }
+    }
+    if (wv == 0) {
+        c_hit = rm_wave_sum(c_hit); c_p = rm_wave_sum(c_p); c_s = rm_wave_sum(c_s);
+        const unsigned bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (lane < 3) U.partials[RM_SLOT_WORDS * bid + lane] = lane == 0 ? c_hit : lane == 1 ? c_p : c_s;
+    }
+}
+
 template <bool ROT, int SCL>
 hipError_t launch_coop_variant(const RmParams &U, dim3 grid, hipStream_t stream) {
     const size_t lds = (size_t)U.n_prims * sizeof(RmPrimDev);
-    if (U.scene_flags & RM_SF_CSG) hipLaunchKernelGGL((rm_coop_kernelN<ROT, SCL, true>), grid, dim3(256), lds, stream, U);
+    const bool fx = U.fx_flags != 0 || U.fx_view != 0 || U.light_model != 0 || U.dom_op != RM_DOM_NONE || U.dst_steps ||
+                    (U.mode == RM_MODE_FRAG && U.shadow_mode != 0);
+    if (fx) hipLaunchKernelGGL((rm_coop_kernelN_fx<ROT, SCL>), grid, dim3(256), lds, stream, U);
+    else if (U.scene_flags & RM_SF_CSG) hipLaunchKernelGGL((rm_coop_kernelN<ROT, SCL, true>), grid, dim3(256), lds, stream, U);
     else                           hipLaunchKernelGGL((rm_coop_kernelN<ROT, SCL, false>), grid, dim3(256), lds, stream, U);
     return hipGetLastError();
 }

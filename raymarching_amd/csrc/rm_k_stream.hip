@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256, 3) void rm_stream_kernelN_coop(const RmParams 
     __shared__ float s_x4[4 * 4 * 64];
     PrimTable<true> t;
     t.T = rm_stage_table(U, 0);
-    const SceneNCoop<ROT, SCL> sc = rm_make_coop_scene<ROT, SCL, CSG>(U, t, (RM_LDS float *)s_xw, (RM_LDS float *)s_x4);
+    const SceneNCoop<ROT, SCL> sc = rm_make_coop_scene<ROT, SCL>(U, t, (RM_LDS float *)s_xw, (RM_LDS float *)s_x4, CSG);
     rm_stream_body<true>(U, sc);
 }
 
