@@ -16,7 +16,10 @@ for n in (3, 4, 5, 6, 7, 8, 9, 12, 13, 16, 20, 24, 28, 32, 48):
             mat.SetVector("_WorldSpaceLightPos0", scenes.WORLD_SPACE_LIGHT_POS0)
             for k, v in scenes.STRESS_FLOATS.items():
                 mat.SetFloat(k, v)
-            mat.SetPrimitives(scenes.stress_primitives(n, seed=0x5EED0000 + n))
+            prims = scenes.stress_primitives(n, seed=0x5EED0000 + n)
+            if os.environ.get("RM_UNTRANSFORMED"):
+                prims = [dict(p, quat=(0.0, 0.0, 0.0, 1.0), scale=(1.0, 1.0, 1.0)) for p in prims]
+            mat.SetPrimitives(prims)
             rt = RenderTexture(w, h, device="cuda:0")
             step = lambda: mat._ck(mat._lib.rm_blit_device(mat.handle, None, None, _ptr(rt.color), _ptr(rt.depth), _ptr(rt.hit), w, h, current_stream_handle("cuda:0")))
             step(); torch.cuda.synchronize()
