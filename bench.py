@@ -478,9 +478,16 @@ def run_multi(args) -> None:
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # before the first GPU call of this process
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
+    if args.backend == "gloo":
+        local_rank %= max(1, torch.cuda.device_count())      # rehearsal: the ranks share what GPUs there are
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    gloo_only = args.backend == "gloo"          # developer rehearsal: several ranks on one GPU, every exchange through the host
+    if gloo_only:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    cdev = "cpu" if gloo_only else dev          # where the small reductions of this function live
     try:
         counts_group = dist.new_group(backend="gloo")           # record counts travel as host tensors
     except Exception as e:                                      # no host-side transport on this node: RCCL carries them too
@@ -563,7 +570,7 @@ def run_multi(args) -> None:
         torch.cuda.synchronize()
 
     def reduce_max(x):
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -573,7 +580,7 @@ def run_multi(args) -> None:
         render(b)
         s = mat.stats()
         tot += [s["n_pixels"], s["n_hit"], s["sum_steps_p"], s["sum_steps_s"]]
-    tt = torch.tensor(tot, dtype=torch.float64, device=dev)
+    tt = torch.tensor(tot, dtype=torch.float64, device=cdev)
     dist.all_reduce(tt, op=dist.ReduceOp.SUM)
     st = dict(zip(["n_pixels", "n_hit", "sum_steps_p", "sum_steps_s"], [int(v) for v in tt.tolist()]))
 
@@ -585,9 +592,25 @@ def run_multi(args) -> None:
     expand[0] = True
     el_g, _ = timed(torch, step_gather, K, W, fence_gather)
     el_g = reduce_max(el_g)
-    sent = torch.tensor([float(gather.bytes_sent)], dtype=torch.float64, device=dev)
+    sent = torch.tensor([float(gather.bytes_sent)], dtype=torch.float64, device=cdev)
     dist.all_reduce(sent, op=dist.ReduceOp.SUM)
     sent_per_step = float(sent.item()) / (2 * (K + W))
+
+    verified = None
+    if args.verify and rank == 0:
+        # rank 0 renders, itself, one pose of every other rank's last batch and compares it with the frame it was sent
+        verified = 0
+        chk = Frame(torch, dev, w, h, 1)
+        for p in range(1, world):
+            theirs = poses_of(N_POSES, p, world)
+            j = len(theirs) - 1                                   # local index of that rank's last pose
+            fcs, c2ws, pos = pose_arrays(scenes, Raymarching, mat, [theirs[j]], w, h)
+            blit_poses(mat, fcs, c2ws, pos, chk, w, h, stream)
+            torch.cuda.synchronize()
+            if not torch.equal(chk.color[0], dense[p, j]):
+                raise SystemExit(f"bench.py --verify: the frame of pose {theirs[j]} delivered by rank {p} differs from rank 0's own rendering")
+            verified += 1
+        del chk
 
     sec = {}
     if world == 2 and not args.headline_only:
@@ -608,17 +631,26 @@ def run_multi(args) -> None:
         hm = torch.empty((rows, bw), dtype=torch.uint8, device=dev)
         rgb = torch.empty((rows, bw, 3), dtype=torch.uint8, device=dev)
         recv = [torch.empty_like(rgb) for _ in range(world)] if rank == 0 else None
+        rgb_h = torch.empty(rgb.shape, dtype=rgb.dtype) if gloo_only else None
+        recv_h = [torch.empty_like(rgb_h) for _ in range(world)] if (gloo_only and rank == 0) else None
 
         def step3(_i):
             m3._ck(m3._lib.rm_shadowmap_directional_device(m3.handle, _fp(corners), _fp(fwd), _ptr(sm_depth), None, bw, bh, stream))
             m3._ck(m3._lib.rm_blit_bands_device(m3.handle, None, None, _ptr(c), _ptr(d), _ptr(hm), bw, bh, band, rank, world, stream))
             m3.pack_rgb(c, rgb)
-            dist.gather(rgb, recv, dst=0)
+            if gloo_only:
+                rgb_h.copy_(rgb)
+                dist.gather(rgb_h, recv_h, dst=0)
+                if rank == 0:
+                    for a, b_ in zip(recv, recv_h):
+                        a.copy_(b_)
+            else:
+                dist.gather(rgb, recv, dst=0)
 
         el3, _ = timed(torch, step3, min(K, 50), min(W, 10), fence)
         el3 = reduce_max(el3)
         s3 = m3.stats()
-        c3 = torch.tensor([float(rays(s3) + bw * bh / world)], dtype=torch.float64, device=dev)
+        c3 = torch.tensor([float(rays(s3) + bw * bh / world)], dtype=torch.float64, device=cdev)
         dist.all_reduce(c3, op=dist.ReduceOp.SUM)
         sec["bands_4k_with_depth_pass_2gpu"] = {"what": "3840x2160 frame as interleaved 8-row bands over 2 GPUs (rm_blit_bands_device) + the full directional "
                                                         "depth pass on each + RCCL gather of the bands as RGB8, per step",
@@ -653,6 +685,8 @@ def run_multi(args) -> None:
                           "what": "the same poses rendered, frames left on the rank that rendered them"},
             "secondary": sec,
         }
+        if verified is not None:
+            out["verified_frames_from_other_ranks"] = verified
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     mat.close()
@@ -676,6 +710,9 @@ def main() -> None:
                     "measured on one GPU: a cap does not make room for the expansion kernels, it only slows the rendering)")
     ap.add_argument("--full-expand", action="store_true", help="N > 1: rank 0 rewrites every dense frame whole at every delivery "
                     "(rm_expand_frames_device) instead of updating the tiles that changed (rm_update_frames_device)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="N > 1: gloo = developer rehearsal of the multi-rank code "
+                    "path with every exchange through the host (several ranks may then share one GPU: set LOCAL_RANK=0 for all)")
+    ap.add_argument("--verify", action="store_true", help="N > 1: rank 0 re-renders one delivered pose per rank and compares the bytes")
     ap.add_argument("--force-multi", action="store_true", help="developer check: run the N > 1 code path with a single rank")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()

@@ -251,7 +251,26 @@ class TileGather:
         self.last_counts = counts
         rec = self.records[t.slot]
 
+        def transfer_through_host():
+            # no device-to-device transport in this group (gloo with device tensors: a rehearsal on one GPU, or a node
+            # without RCCL peer access): the records cross as host tensors, blocking, peers in rank order
+            bufs = {}
+            if self.rank == self.root:
+                for p in range(self.world):
+                    if p != self.root and counts[p] > 0:
+                        h = torch.empty((counts[p], RECORD_WORDS), dtype=torch.int32)
+                        dist.recv(h, self._global(p), group=self.group)
+                        bufs[p] = h.to(self.device)
+            elif mine > 0:
+                dist.send(rec[:mine].cpu(), self._global(self.root), group=self.group)
+                self.bytes_sent += mine * RECORD_WORDS * 4
+            if self.rank == self.root and on_received is not None:
+                for p in range(self.world):
+                    on_received(p, rec if p == self.root else bufs.get(p), mine if p == self.root else counts[p])
+
         def transfer():
+            if self.cuda and self.world > 1 and dist.get_backend(self.group) == "gloo":
+                return transfer_through_host()
             ops, bufs = [], {}
             if self.rank == self.root:
                 for p in range(self.world):
