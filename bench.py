@@ -374,6 +374,22 @@ def run_single(args) -> None:
                                                             "march loops; within the port's tolerance of the strict frame, not bit-equal"})
         m7.close()
 
+        # ---- the headline frame as Graphics.Blit(src, dest, mat) of the reference passes it: with a source image (what miss
+        # pixels show) and the camera's depth texture (here: everything at the far plane, so the same rays are marched)
+        m8 = default_material(w, h)
+        src8 = torch.randint(0, 256, (h, w, 4), dtype=torch.uint8, device=dev)
+        sd8 = torch.full((h, w), 1000.0, dtype=torch.float32, device=dev)
+
+        def step8(_i):
+            m8._ck(lib.rm_blit_device(m8.handle, _ptr(src8), _ptr(sd8), _ptr(fr.color), _ptr(fr.depth), _ptr(fr.hit), w, h, stream))
+
+        el, ms = timed(torch, step8, Ks, Ws)
+        s8 = m8.stats()
+        sec["with_source_image_and_depth_texture_4k"] = block(s8, ms, {"what": f"{w}x{h}, the headline frame with _MainTex and the depth texture bound "
+                                                                               "(13 B/pixel of reads on top of the 9 B/pixel written)"})
+        m8.close()
+        del src8, sd8
+
         # ---- 4K with the directional depth pass (configuration 3 on one GPU) ----------------------------------
         m4 = default_material(w, h)
         t = Transform(position=vec3(-3, 3, 9), rotation=scenes.shadow_camera().transform.rotation, lossyScale=vec3(14, 8, 1))

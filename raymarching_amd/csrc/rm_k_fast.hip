@@ -30,6 +30,7 @@ hipError_t launch_fast_variant(const RmParams &U, unsigned blocks, hipStream_t s
     const int shape = rm_queue_shape(U);
     if (shape == 1) return launch_fast_shape<ROT, SCL, 1>(U, blocks, stream, blocks_per_cu);
     if (shape == 2) return launch_fast_shape<ROT, SCL, 2>(U, blocks, stream, blocks_per_cu);
+    if (shape == 3) return launch_fast_shape<ROT, SCL, 3>(U, blocks, stream, blocks_per_cu);
     return launch_fast_shape<ROT, SCL, 0>(U, blocks, stream, blocks_per_cu);
 }
 

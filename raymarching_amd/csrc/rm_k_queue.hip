@@ -37,6 +37,7 @@ hipError_t launch_queue_variant(const RmParams &U, unsigned blocks, hipStream_t 
         int n4 = 0, nN = 0;
         const size_t lds4 = (size_t)U.queue.bitmap_words * 4;
         hipError_t e = shape == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, rm_queue_kernel4_plain<ROT, SCL, 1>, 256, lds4)
+                     : shape == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, rm_queue_kernel4_plain<ROT, SCL, 3>, 256, lds4)
                      : shape == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, rm_queue_kernel4_plain<ROT, SCL, 2>, 256, lds4)
                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, rm_queue_kernel4<ROT, SCL>, 256, lds4);
         if (e != hipSuccess) return e;
@@ -49,6 +50,7 @@ hipError_t launch_queue_variant(const RmParams &U, unsigned blocks, hipStream_t 
     if (U.n_prims > 0) hipLaunchKernelGGL((rm_queue_kernelN<ROT, SCL>), dim3(blocks), dim3(256), lds, stream, U);
     else if (shape == 1) hipLaunchKernelGGL((rm_queue_kernel4_plain<ROT, SCL, 1>), dim3(blocks), dim3(256), lds, stream, U);
     else if (shape == 2) hipLaunchKernelGGL((rm_queue_kernel4_plain<ROT, SCL, 2>), dim3(blocks), dim3(256), lds, stream, U);
+    else if (shape == 3) hipLaunchKernelGGL((rm_queue_kernel4_plain<ROT, SCL, 3>), dim3(blocks), dim3(256), lds, stream, U);
     else               hipLaunchKernelGGL((rm_queue_kernel4<ROT, SCL>), dim3(blocks), dim3(256), lds, stream, U);
     return hipGetLastError();
 }
@@ -56,11 +58,13 @@ hipError_t launch_queue_variant(const RmParams &U, unsigned blocks, hipStream_t 
 }  // namespace
 
 int rm_queue_shape(const RmParams &U) {
-    const bool plain = U.body == RM_BODY_PRIMS && U.n_prims == 0 && U.mode == RM_MODE_FRAG && U.n_parts == 1 && !U.src && !U.sdepth &&
-                       U.dst_rgba && U.dst_depth && U.dst_hit && U.inv_w != 0.0f && U.inv_h != 0.0f;
-    if (!plain) return 0;
-    if (!U.views && U.n_poses == 1) return 1;
-    return U.views ? 2 : 0;
+    const bool base = U.body == RM_BODY_PRIMS && U.n_prims == 0 && U.mode == RM_MODE_FRAG && U.n_parts == 1 &&
+                      U.dst_rgba && U.dst_depth && U.dst_hit && U.inv_w != 0.0f && U.inv_h != 0.0f;
+    if (!base) return 0;
+    const bool single = !U.views && U.n_poses == 1;
+    if (!U.src && !U.sdepth) return single ? 1 : (U.views ? 2 : 0);
+    if (U.src && U.sdepth && single) return 3;
+    return 0;
 }
 
 hipError_t rm_launch_queue(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu) {

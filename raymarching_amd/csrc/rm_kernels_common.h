@@ -134,7 +134,7 @@ RM_DI void rm_setup_ray(const RmParams &U, int x, int yl, int pose, V3 &ro, V3 &
         rd = mk3(U.ortho_fwd[0], U.ortho_fwd[1], U.ortho_fwd[2]);
     } else {
         // rasteriser interpolation of vert's viewDir (cginc:26-33) to the pixel centre
-        if (SHAPE == 1 || (!PLAIN && use_sv)) {
+        if (SHAPE == 1 || SHAPE == 3 || (!PLAIN && use_sv)) {
             typedef float rm_f4 __attribute__((ext_vector_type(4)));
             const volatile RM_LDS rm_f4 *q = (const volatile RM_LDS rm_f4 *)sv;      // four ds_read_b128, one wait
             const rm_f4 a = q[0], b = q[1], c = q[2], d = q[3];
@@ -150,7 +150,7 @@ RM_DI void rm_setup_ray(const RmParams &U, int x, int yl, int pose, V3 &ro, V3 &
         }
     }
     depth = U.far_plane;                                          // shader:154
-    if (!PLAIN && U.mode == RM_MODE_FRAG && U.sdepth) depth = U.sdepth[gidx];
+    if (SHAPE == 3 || (!PLAIN && U.mode == RM_MODE_FRAG && U.sdepth)) depth = U.sdepth[gidx];
     depth = fminf(depth, U.max_dist);                             // cginc:368
 }
 
@@ -205,7 +205,7 @@ RM_DI PixelOut rm_compute_pixel(const RmParams &U, const S &sc, int x, int yl, i
             float cg = ((s.y * ndl) * shadow) * ao;
             float cb = ((s.z * ndl) * shadow) * ao;
             out.rgba = rm_unorm8(cr) | (rm_unorm8(cg) << 8) | (rm_unorm8(cb) << 16) | 0xFF000000u;
-        } else if (!PLAIN && U.src) {
+        } else if (rm_shape<S>::value == 3 || (!PLAIN && U.src)) {
             out.rgba = reinterpret_cast<const uint32_t *>(U.src)[gidx] | 0xFF000000u;
         } else {
             out.rgba = U.bg_rgba8;
@@ -523,7 +523,7 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
     rm_lds_cfloat sv = (rm_lds_cfloat)s_view;
     constexpr int SHAPE = rm_shape<S>::value;
     constexpr bool PLAIN = SHAPE != 0;
-    const bool use_sv = SHAPE == 1 || (!PLAIN && U.views == nullptr);
+    const bool use_sv = SHAPE == 1 || SHAPE == 3 || (!PLAIN && U.views == nullptr);
     // this frame's heavy bitmap -> LDS
     if (Q.use_history) {
         const unsigned *bitmap_cur = Q.bitmaps + (size_t)Q.hv_cur * Q.bitmap_words;

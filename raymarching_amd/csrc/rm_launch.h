@@ -41,7 +41,8 @@ hipError_t rm_reduce_stats(const unsigned *partials, unsigned n_blocks, unsigned
 hipError_t rm_launch_queue(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu);
 // the instantiation rm_launch_queue picks for U: 1 = the plain frame (4-slot scene, fragment pass, whole frame, one pose with
 // the view in the arguments, no source image or depth texture, all three output planes), 2 = the same for a batch of poses
-// with their views in device memory, 0 = the general kernel
+// with their views in device memory, 3 = as 1 but with source image and depth texture (the reference's Blit), 0 = the
+// general kernel
 int rm_queue_shape(const RmParams &U);
 int rm_variant_index(const RmParams &U);
 

@@ -271,6 +271,7 @@ CASES = [
     Case("default_1920x1080", 1920, 1080, heavy=True),
     Case("default_3840x2160", 3840, 2160, heavy=True),
     Case("default_src_depth_333x187", 333, 187, src=True, sdepth=True),      # ragged size, _MainTex + depth texture
+    Case("default_src_depth_640x360", 640, 360, src=True, sdepth=True),      # what Graphics.Blit(src, dest, mat) passes, at a size with exact reciprocals
     Case("orbit_k5_480x270", 480, 270, setup=_orbit(5)),
     Case("orbit_k23_480x270", 480, 270, setup=_orbit(23)),
     Case("orbit_k40_480x270", 480, 270, setup=_orbit(40)),
