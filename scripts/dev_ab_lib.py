@@ -38,6 +38,11 @@ def main():
     depth = torch.empty((h, w), dtype=torch.float32, device="cuda")
     hit = torch.empty((h, w), dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
+    src = sd = None                                     # tex=1: bind a source image and a depth texture (all at the far plane)
+    if opts.get("tex") == "1":
+        tsrc = torch.randint(0, 256, (h, w, 4), dtype=torch.uint8, device="cuda")
+        tsd = torch.full((h, w), 1000.0, dtype=torch.float32, device="cuda")
+        src, sd = tsrc.data_ptr(), tsd.data_ptr()
     ctxs = []
     for p in libs:
         l = load(p)
@@ -52,12 +57,12 @@ def main():
     for rnd in range(3):
         for p, l, c in ctxs:
             for _ in range(30):
-                assert l.rm_blit_device(c, None, None, color.data_ptr(), depth.data_ptr(), hit.data_ptr(), w, h, stream) == 0
+                assert l.rm_blit_device(c, src, sd, color.data_ptr(), depth.data_ptr(), hit.data_ptr(), w, h, stream) == 0
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(steps):
-                l.rm_blit_device(c, None, None, color.data_ptr(), depth.data_ptr(), hit.data_ptr(), w, h, stream)
+                l.rm_blit_device(c, src, sd, color.data_ptr(), depth.data_ptr(), hit.data_ptr(), w, h, stream)
             e1.record()
             torch.cuda.synchronize()
             print(f"round {rnd} {os.path.basename(p):28s} {w}x{h}: {e0.elapsed_time(e1) / steps * 1e3:8.1f} us/frame", flush=True)
