@@ -443,9 +443,14 @@ def run_single(args) -> None:
         per_eval = sum(47 + (8, 19, 12, 15)[p["type"]] for p in prims) + 13 * (len(prims) - 1)
         fl5 = (per_eval + 11.0) * s5["sum_steps_p"] + (per_eval + 14.0) * s5["sum_steps_s"] + s5["n_hit"] * (7.0 * per_eval + 36.0 * (len(prims) - 1) + 77.0)
         sec["stress256_1080p"] = {"what": "256 smooth-union primitives (rotated, scaled), _MaxSteps 512, grazing camera, 1920x1080; exact kernel "
-                                          "(automatic choice: one block per 8x8 tile, its four waves split the table)",
+                                          "(automatic choice: one block per 8x8 tile, its four waves split the table; the marches skip the "
+                                          "subtrees that provably cannot change a bit of the result)",
                                   "ms_per_step": ms, "Mrays_per_s": rays(s5) / (ms * 1e-3) / 1e6, "flops_per_eval": per_eval,
                                   "tflops": fl5 / (ms * 1e-3) / 1e12, "frac_of_peak": fl5 / (ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS}
+        m5.SetFloat("_RmTableSkip", 0.0)                      # the same kernel walking the whole table at every step
+        el, ms0 = timed(torch, step5, 3, 1)
+        sec["stress256_1080p"]["full_table_walk"] = {"ms_per_step": ms0, "frac_of_peak": fl5 / (ms0 * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS}
+        m5.SetFloat("_RmTableSkip", 1.0)
         m5.set_kernel(1)                                      # the exact one-wave-per-tile kernel, for comparison
         el, ms1 = timed(torch, step5, 3, 1)
         sec["stress256_1080p"]["one_wave_per_tile_kernel"] = {"ms_per_step": ms1, "frac_of_peak": fl5 / (ms1 * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS}

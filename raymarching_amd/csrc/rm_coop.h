@@ -40,6 +40,10 @@ struct SceneNCoop {
     RM_DI float w(V3 p) const {
         float mine = 0.0f;
         if (part.n > 0) mine = part.w(p);
+        return finish(mine);
+    }
+    // the value of this wave's chunk meets the other three
+    RM_DI float finish(float mine) const {
         RM_LDS float *b = xw + parity * 256u;
         b[wv * 64u + lane] = mine;
         __syncthreads();

@@ -1,0 +1,56 @@
+// rm_k_skip.hip -- plain smooth-union tables on the shared-tile kernel with exact culling (rm_skip.h): one launch block per
+// 8x8 pixel tile, its four waves march the same 64 rays and each walks a quarter of the table, skipping the left subtrees
+// that provably cannot change a bit of the result.  Frames are bit-identical to the other exact kernels'.  Compiled
+// without the SLP vectoriser like the other table kernels.
+#include "rm_kernels_common.h"
+#include "rm_coop.h"
+#include "rm_skip.h"
+
+namespace {
+
+template <bool ROT, int SCL>
+__global__ __launch_bounds__(256, 4) void rm_coop_kernelN_skip(const RmParams U) {
+    __shared__ float s_xw[2 * 4 * 64];
+    __shared__ float s_x4[4 * 4 * 64];
+    PrimTable<true> t;
+    t.T = rm_stage_table(U, 0);                                           // ends with a __syncthreads()
+    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const SceneNCoop<ROT, SCL> coop = rm_make_coop_scene<ROT, SCL>(U, t, (RM_LDS float *)s_xw, (RM_LDS float *)s_x4, false);
+    const int chunk = (1 << (32 - __builtin_clz((unsigned)U.n_prims - 1u))) >> 2;
+    rmx::SceneNSkip<ROT, SCL> sc(coop, chunk);
+    unsigned c_hit = 0, c_p = 0, c_s = 0;
+    const int x = blockIdx.x * 8 + (int)(lane & 7u), yl = blockIdx.y * 8 + (int)(lane >> 3);
+    const bool in_bounds = x < U.w && yl < U.rows;
+    PixelOut po = rmx::compute_pixel(U, sc, coop, in_bounds ? x : U.w - 1, in_bounds ? yl : U.rows - 1, (int)blockIdx.z, in_bounds,
+                                     c_hit, c_p, c_s);
+    if (wv == 0) {
+        if (in_bounds) rm_store_pixel(U, po);                             // the four waves hold the same pixels
+        c_hit = rm_wave_sum(c_hit); c_p = rm_wave_sum(c_p); c_s = rm_wave_sum(c_s);
+        const unsigned bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (lane < 3) U.partials[RM_SLOT_WORDS * bid + lane] = lane == 0 ? c_hit : lane == 1 ? c_p : c_s;
+    }
+}
+
+template <bool ROT, int SCL>
+hipError_t launch_skip_variant(const RmParams &U, dim3 grid, hipStream_t stream) {
+    const size_t lds = (size_t)U.n_prims * sizeof(RmPrimDev);
+    hipLaunchKernelGGL((rm_coop_kernelN_skip<ROT, SCL>), grid, dim3(256), lds, stream, U);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool rm_skip_applies(const RmParams &U) {
+    if (U.body != RM_BODY_PRIMS || U.lds_prims != U.n_prims || U.n_prims < 3 || (U.scene_flags & RM_SF_CSG)) return false;
+    const int chunk = (1 << (32 - __builtin_clz((unsigned)U.n_prims - 1u))) >> 2;
+    return chunk >= RM_SKIP_MIN_CHUNK && chunk <= RM_SKIP_MAX_CHUNK;
+}
+
+// plain smooth-union tables staged whole in LDS whose quarter is 16 to 64 primitives (33 to 256 primitives); same grid and
+// counter slots as rm_launch_coop_tiles
+hipError_t rm_launch_coop_skip_tiles(const RmParams &U, hipStream_t stream) {
+    if (U.w <= 0 || U.rows <= 0 || U.n_poses <= 0 || !rm_skip_applies(U)) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((U.w + 7) / 8), (unsigned)((U.rows + 7) / 8), (unsigned)U.n_poses);
+    if (grid.y > 65535u || grid.z > 65535u) return hipErrorInvalidValue;
+    RM_DISPATCH_VARIANT(launch_skip_variant, U, U, grid, stream);
+}

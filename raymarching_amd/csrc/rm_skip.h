@@ -1,0 +1,251 @@
+#pragma once
+// rm_skip.h -- exact culling for plain smooth-union tables in the shared-tile kernel: a march step evaluates only the
+// primitives that can reach the result, and the result keeps every bit.
+//
+// smin(a, b, .5) (Assets/Raymarching.cginc:110-113) is h = clamp(.5 + (b - a), 0, 1); lerp(b, a, h) - .5*h*(1-h), evaluated
+// here as e = b - a; (b - h*e) - (.5*h)*(1 - h) (rm_smin_w).  Once b <= a - .5 the sum .5 + e rounds to at most 0, the
+// clamp gives h = 0 and the value is (b - 0*e) - 0*1: the RIGHT operand, bit for bit, whatever finite value the left operand
+// has.  (b = -0 would come back as +0; a leaf of a plain union with positive scales never returns -0 -- its last operation
+// is a difference or a sum of values that are not -0, times a positive factor -- and a node returns -0 only if b is.)
+// The other side is not exact: b - 1*(b - a) is not a in floating point.  So a node's LEFT subtree need not be evaluated if
+// its value is known to be at least .5 above the right subtree's.
+//
+// The bounds: every leaf rotate(p - pos, q) / scale -> primitive -> * min(scale) (cginc:336-354) is 1-Lipschitz in p
+// (the primitives are Euclidean distance functions; |grad| <= min(scale) / min(scale), scales positive), and
+// min(a, b) - .125 <= smin(a, b) <= min(a, b).  Before an evaluation the wave takes the bounding box of its marching rays'
+// sample points and evaluates the 64 leaves of its chunk at the box centre, one leaf per lane: that value minus / plus the
+// half diagonal bounds the leaf on the whole box from below / above.  A butterfly of minima gives both bounds for every
+// aligned block of 2^l leaves (the lower one less .126 per level), and a left block is skipped when its sibling's upper
+// bound is .5 below its lower bound.  A margin of .01 covers the rounding of the fp32 evaluations with all coordinates
+// and distances below 1000; beyond that, or with anything not finite, nothing is skipped.  The decisions are taken before
+// the walk (as a bit mask over the leaves), so the walk is SceneN::tree's with absent operands: straight-line groups of four
+// with their loads issued together, a binary-counter stack over the groups.  The last leaf of a chunk is always evaluated.
+#include "rm_kernels_common.h"
+#include "rm_coop.h"
+
+namespace rmx {
+
+// wave-wide float min / max with all 64 lanes active; the result is in every lane
+template <bool MAX> RM_DI float wave_reduce(float v) {
+    float t;
+#define RM_RSTEP(ctrl)                                                                                             \
+    t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true));                  \
+    v = MAX ? fmaxf(v, t) : fminf(v, t);
+    RM_RSTEP(0xB1) RM_RSTEP(0x4E) RM_RSTEP(0x141) RM_RSTEP(0x140)
+#undef RM_RSTEP
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return MAX ? fmaxf(fmaxf(a, b), fmaxf(c, d)) : fminf(fminf(a, b), fminf(c, d));
+}
+
+#define RM_SKIP_LEVELS 5          // levels of the stack over groups of four leaves: chunks of up to 64 leaves
+#define RM_SKIP_MAX_CHUNK 64      // one threshold per lane
+#define RM_SKIP_MIN_CHUNK 32
+#define RM_SKIP_RANGE 1000.0f     // coordinates and distances beyond this: no culling (the margin below is sized for it)
+
+// the record of leaf i as this lane's own (lanes read different records; PrimTable::get is for wave-uniform indices)
+RM_DI RmPrimDev lane_record(RmLdsPrimPtr T, int i) {
+    union { RmPrimDev p; rm_u4 v[sizeof(RmPrimDev) / 16]; } u;
+#pragma unroll
+    for (int j = 0; j < (int)(sizeof(RmPrimDev) / 16); j++) u.v[j] = T[i * (int)(sizeof(RmPrimDev) / 16) + j];
+    return u.p;
+}
+
+template <bool ROT, int SCL>
+struct SceneNSkip {
+    typedef SceneN<ROT, SCL, true> Part;
+    const SceneNCoop<ROT, SCL> &coop;
+    bool cullable;                 // this wave's chunk is complete and has RM_SKIP_MIN_CHUNK..RM_SKIP_MAX_CHUNK leaves
+    int groups;                    // leaves of the chunk / 4, a power of two
+    unsigned long long all;        // one bit per leaf of the chunk
+    unsigned long long mask;       // the leaves the next evaluation visits
+
+    RM_DI SceneNSkip(const SceneNCoop<ROT, SCL> &c, int chunk) : coop(c) {
+        cullable = c.part.n == chunk && chunk >= RM_SKIP_MIN_CHUNK && chunk <= RM_SKIP_MAX_CHUNK;
+        groups = chunk >> 2;
+        all = chunk >= 64 ? ~0ull : ((1ull << chunk) - 1ull);
+        mask = all;
+    }
+
+    // Every lane of the wave calls this; `active` lanes evaluate the scene at q next.
+    RM_DI void prepare(bool active, V3 q) {
+        mask = all;
+        if (!cullable || !__any(active)) return;
+        const float inf = __builtin_inff();
+        const float lox = wave_reduce<false>(active ? q.x : inf), hix = wave_reduce<true>(active ? q.x : -inf);
+        const float loy = wave_reduce<false>(active ? q.y : inf), hiy = wave_reduce<true>(active ? q.y : -inf);
+        const float loz = wave_reduce<false>(active ? q.z : inf), hiz = wave_reduce<true>(active ? q.z : -inf);
+        const float cx = 0.5f * (lox + hix), cy = 0.5f * (loy + hiy), cz = 0.5f * (loz + hiz);
+        const float ex = hix - lox, ey = hiy - loy, ez = hiz - loz;
+        // every marching sample point is within hd of the centre (rounded up), .01 for the rounding of the evaluations
+        const float hd = 0.5f * __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez) * 1.0001f + 1e-5f * (fabsf(cx) + fabsf(cy) + fabsf(cz)) + 0.01f;
+        const int j = (int)coop.lane;
+        const bool mine = j < 4 * groups;
+        float lb = inf, ub = inf;
+        bool bad = !(fabsf(cx) + fabsf(cy) + fabsf(cz) + hd <= RM_SKIP_RANGE);          // also true for NaN
+        if (mine) {
+            const RmPrimDev P = lane_record(coop.part.tab.T, j);
+            const float d = rm_prim_typed<ROT, SCL>(P, P.type & RM_TYPE_MASK, mk3(cx, cy, cz), coop.part.tiny);
+            // (a negative scale would make min(scale) the largest in magnitude and the leaf steeper than 1)
+            bad = bad || !(fabsf(d) + hd <= RM_SKIP_RANGE) || !(fabsf(P.px) + fabsf(P.py) + fabsf(P.pz) <= RM_SKIP_RANGE) ||
+                  (SCL != RM_SCL_UNIT && !(P.ms > 0.0f));
+            lb = d - hd;
+            ub = d + hd;
+        }
+        if (__any(bad)) return;
+#ifndef RM_SKIP_NEVER
+        // level l: the aligned blocks of 2^l leaves meet their siblings; a left block (bit l of j clear) is skipped if the
+        // right one's upper bound is .5 below its lower bound, which loses .126 per level of smin inside it
+        bool skip = false;
+#pragma unroll
+        for (int l = 0; l < 6; l++) {
+            const float sub = __shfl_xor(ub, 1 << l), slb = __shfl_xor(lb, 1 << l);
+            skip = skip || (!((j >> l) & 1) && sub + (0.5f + 0.126f * (float)l) <= lb);
+            ub = fminf(ub, sub);
+            lb = fminf(lb, slb);
+        }
+        mask = __ballot(mine && !skip);
+#endif
+    }
+
+    RM_DI float leaf(int i, V3 p) const {
+        float s;
+        int tw;
+        return coop.part.template leaf_w<false>(i, p, s, tw);
+    }
+    // group g of four leaves with the leaves m4 names (bit 3, the last leaf, is set whenever any is): an absent left
+    // operand leaves smin(left, right) = right.  (Fetching all four records up front whatever m4 says was measured: no gain.)
+    RM_DI float group(int g, unsigned m4, V3 p) const {
+        const int i = g << 2;
+        if (m4 == 15u) {
+            const float a = leaf(i, p), b = leaf(i + 1, p), c = leaf(i + 2, p), d = leaf(i + 3, p);
+            return rm_smin_w(rm_smin_w(a, b), rm_smin_w(c, d));
+        }
+        const float d = leaf(i + 3, p);
+        const float cd = (m4 & 4u) ? rm_smin_w(leaf(i + 2, p), d) : d;
+        if (!(m4 & 2u)) return cd;
+        const float b = leaf(i + 1, p);
+        const float ab = (m4 & 1u) ? rm_smin_w(leaf(i, p), b) : b;
+        return rm_smin_w(ab, cd);
+    }
+    // this wave's chunk: the binary-counter walk of SceneN::tree over the groups that are present
+    RM_DI float walk(V3 p) const {
+        float st[RM_SKIP_LEVELS];
+#pragma unroll
+        for (int l = 0; l < RM_SKIP_LEVELS; l++) st[l] = 0.0f;
+        unsigned pres = 0;                                      // bit l: st[l] holds a subtree (else it was skipped)
+        float v = 0.0f;
+        for (int g = 0; g < groups; g++) {
+            const unsigned m4 = (unsigned)(mask >> (4 * g)) & 15u;
+            const int merges = __builtin_ctz(~(unsigned)g);     // trailing ones of g = finished lower levels
+            const unsigned below = (1u << merges) - 1u;
+            if (m4 == 0u) {                                     // a skipped block is a whole left operand: nothing below it is kept
+                pres &= ~(below | (1u << merges));
+                continue;
+            }
+            v = group(g, m4, p);
+#pragma unroll
+            for (int l = 0; l < RM_SKIP_LEVELS - 1; l++)
+                if (l < merges && ((pres >> l) & 1u)) v = rm_smin_w(st[l], v);
+#pragma unroll
+            for (int l = 0; l < RM_SKIP_LEVELS; l++) if (l == merges) st[l] = v;
+            pres = (pres & ~below) | (1u << merges);
+        }
+        return v;
+    }
+    // scene distance at p for the marches; prepare() must have seen p
+    RM_DI float eval(V3 p) const {
+        float mine = 0.0f;
+        if (cullable) mine = walk(p);
+        else if (coop.part.n > 0) mine = coop.part.w(p);
+        return coop.finish(mine);
+    }
+};
+
+// The fragment program for one pixel with the two marches on the culled evaluation.  Every lane of the wave calls this
+// (lanes outside the frame with in_bounds = false and the coordinates of some pixel inside): the bounds are built by the
+// whole wave.  Operations and their order are those of rm_compute_pixel.
+template <class SKIP, class STRICT>
+RM_DI PixelOut compute_pixel(const RmParams &U, SKIP &sc, const STRICT &strict, int x, int yl, int pose, bool in_bounds,
+                             unsigned &c_hit, unsigned &c_p, unsigned &c_s) {
+    PixelOut out;
+    V3 ro, rd;
+    float depth;
+    size_t gidx;
+    rm_setup_ray(U, x, yl, pose, ro, rd, depth, gidx, out.oidx);
+    const float sf = rm_vgpr(U.step_factor), kc = rm_vgpr(.0025f);
+
+    // ---- raymarch (cginc:367-392) ----
+    bool active = in_bounds && U.n_steps > 0;
+    float dm = 0.0f, adts = __builtin_inff(), contact = 0.0f;
+    unsigned evals = 0;
+    for (int i = 0; i < U.n_steps; i++) {
+        if (!__any(active)) break;
+        const V3 cp = mk3(ro.x + rd.x * dm, ro.y + rd.y * dm, ro.z + rd.z * dm);
+        sc.prepare(active, cp);
+        const float v = sc.eval(cp);
+        if (active) {
+            adts = fabsf(v);
+            evals++;
+            dm = dm + adts * sf;
+            contact = dm * kc;
+            if (adts < contact || dm > depth) active = false;
+        }
+    }
+    const bool hit = in_bounds && adts < contact;
+    c_p += evals;
+    c_hit += hit ? 1u : 0u;
+    out.depth = dm;
+    out.hit = hit ? 1u : 0u;
+    out.rgba = 0;
+    out.steps = 0;
+
+    if (U.mode == RM_MODE_FRAG) {
+        const V3 L = mk3(rm_vgpr(U.light[0]), rm_vgpr(U.light[1]), rm_vgpr(U.light[2]));
+        // ---- normal, colour: the whole table (shader:63-67, 193) ----
+        const V3 hp = mk3(ro.x + rd.x * dm, ro.y + rd.y * dm, ro.z + rd.z * dm);
+        V3 n = mk3(0.0f, 0.0f, 0.0f), raw = n;
+        V4 s;
+        s.x = s.y = s.z = s.w = 0.0f;
+        if (hit) {
+            raw = rm_normal_raw(U, strict, hp);
+            n = rm_normalize(raw);
+            s = strict.full(hp);
+        }
+        // ---- getshadow (shader:102-123), hit lanes only ----
+        const float c0 = contact;
+        const V3 p = mk3(hp.x + (n.x * c0) * 2.0f, hp.y + (n.y * c0) * 2.0f, hp.z + (n.z * c0) * 2.0f);
+        bool sactive = hit && U.n_steps > 0;
+        float sdm = 0.0f, res = 1.0f;
+        unsigned sev = 0;
+        for (int i = 0; i < U.n_steps; i++) {
+            if (!__any(sactive)) break;
+            const V3 cp = mk3(p.x + L.x * sdm, p.y + L.y * sdm, p.z + L.z * sdm);
+            sc.prepare(sactive, cp);
+            const float dts = sc.eval(cp);
+            if (sactive) {
+                sev++;
+                res = fminf(res, 16.0f * dts / sdm);
+                const float a = fabsf(dts);
+                sdm = sdm + a * sf;
+                const float ct = sdm * kc;
+                if (a < ct || sdm > U.shadow_depth) sactive = false;
+            }
+        }
+        c_s += sev;
+        if (hit) {
+            const float shadow = res * 0.75f + .25f;
+            const float ndl = rm_dot3(n, L) * .5f + .5f;
+            const float ao = rm_clamp01(rm_len3(mk3(raw.x / U.nss_raw, raw.y / U.nss_raw, raw.z / U.nss_raw)));
+            out.rgba = rm_unorm8(((s.x * ndl) * shadow) * ao) | (rm_unorm8(((s.y * ndl) * shadow) * ao) << 8) |
+                       (rm_unorm8(((s.z * ndl) * shadow) * ao) << 16) | 0xFF000000u;
+        } else if (in_bounds) {
+            out.rgba = U.src ? (reinterpret_cast<const uint32_t *>(U.src)[gidx] | 0xFF000000u) : U.bg_rgba8;
+        }
+    }
+    return out;
+}
+
+}  // namespace rmx

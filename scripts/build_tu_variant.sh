@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../raymarching_amd/csrc"
 mkdir -p ../variants
 TU=$1; shift
-FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function"
+FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function $RM_EXTRA_FLAGS"
 OTHERS=$(ls rm_k_*.o rm_scratch.o rm_api.o | grep -v "^rm_k_$TU.o$" | tr '\n' ' ')
 while [ $# -ge 2 ]; do
   tag=$1; defs=$2; shift 2

@@ -8,7 +8,7 @@ import math
 import numpy as np
 
 from raymarching_amd import Material, Raymarching, ShadowMap, ShadowMapDirectional, scenes
-from raymarching_amd.unity import F, Transform, quat_angle_axis, quat_mul, vec3
+from raymarching_amd.unity import Camera, F, Transform, quat_angle_axis, quat_mul, vec3
 
 
 def _base(mat: Material, w: int, h: int, camera=None, transforms=None) -> Raymarching:
@@ -382,6 +382,59 @@ CASES = [
 BY_NAME = {c.name: c for c in CASES}
 
 
+def _stress_cam(position, euler_deg=(2.0, 0.0, 0.0), floats=None, vectors=None):
+    """the stress-table set-up seen from another camera, optionally with other march uniforms"""
+    def f(case, mat):
+        rot = quat_mul(quat_angle_axis(euler_deg[1], (0, 1, 0)), quat_angle_axis(euler_deg[0], (1, 0, 0)))
+        cam = Camera(transform=Transform(position=vec3(*position), rotation=rot), fieldOfView=80.0, aspect=case.w / case.h,
+                     nearClipPlane=0.3, farClipPlane=100000.0)
+        _base(mat, case.w, case.h, camera=cam)
+        for k, v in dict(scenes.STRESS_FLOATS, **(floats or {})).items():
+            mat.SetFloat(k, v)
+        for k, v in (vectors or {}).items():
+            mat.SetVector(k, np.asarray(v, dtype=F))
+    return f
+
+
+def _edited(prims, edits):
+    out = [dict(p) for p in prims]
+    for i, e in edits.items():
+        out[i] = dict(out[i], **e)
+    return out
+
+
+# Plain smooth-union tables of 65 to 256 primitives take the shared-tile kernel with exact culling in the marches: table
+# sizes that give full, partial and one-leaf quarters, the variants without rotation / scale, a camera inside the slab, the
+# guards (coordinates beyond the range the rounding margin is sized for, a negative and a zero scale, an enormous
+# primitive, a camera that is not a number) and a depth pass.  Compared with the oracle on the GPU only (no golden entry).
+SKIP_CASES = [
+    Case("skip_stress65_160x90", 160, 90, setup=_stress, prims=scenes.stress_primitives(65, seed=0x5EED0041)),
+    Case("skip_stress128_160x90", 160, 90, setup=_stress, prims=scenes.stress_primitives(128, seed=0x5EED0080)),
+    Case("skip_stress200_160x90", 160, 90, setup=_stress, prims=scenes.stress_primitives(200, seed=0x5EED00C8)),
+    Case("skip_stress256_inside_160x90", 160, 90, setup=_stress_cam((0.3, 0.1, -2.0), (0.0, 25.0, 0.0)), prims=scenes.stress_primitives(256)),
+    Case("skip_stress256_above_128x72", 128, 72, setup=_stress_cam((0.0, 9.0, 0.0), (88.0, 0.0, 0.0)), prims=scenes.stress_primitives(256)),
+    Case("skip_stress128_far_camera_96x54", 96, 54, prims=scenes.stress_primitives(128, seed=0x5EED0080),
+         setup=_stress_cam((0.0, 1100.0, 0.0), (90.0, 0.0, 0.0), floats={"_MaxDist": 1200.0, "_MaxSteps": 64.0, "_StepFactor": 0.9})),
+    Case("skip_stress128_untransformed_128x72", 128, 72, setup=_stress,
+         prims=[dict(p, quat=(0.0, 0.0, 0.0, 1.0), scale=(1.0, 1.0, 1.0)) for p in scenes.stress_primitives(128, seed=0x5EED0080)]),
+    Case("skip_stress128_scaled_only_128x72", 128, 72, setup=_stress,
+         prims=[dict(p, quat=(0.0, 0.0, 0.0, 1.0)) for p in scenes.stress_primitives(128, seed=0x5EED0080)]),
+    Case("skip_stress128_rotated_only_128x72", 128, 72, setup=_stress,
+         prims=[dict(p, scale=(1.0, 1.0, 1.0)) for p in scenes.stress_primitives(128, seed=0x5EED0080)]),
+    Case("skip_stress128_negative_scale_128x72", 128, 72, setup=_stress,
+         prims=_edited(scenes.stress_primitives(128, seed=0x5EED0080), {5: {"scale": (-1.2, 0.8, 1.0)}, 77: {"scale": (0.7, -0.6, -1.1)}})),
+    Case("skip_stress128_zero_scale_96x54", 96, 54, setup=_stress,
+         prims=_edited(scenes.stress_primitives(128, seed=0x5EED0080), {40: {"scale": (1.0, 0.0, 1.0)}})),
+    Case("skip_stress128_enormous_sphere_96x54", 96, 54, setup=_stress,
+         prims=_edited(scenes.stress_primitives(128, seed=0x5EED0080), {64: {"type": 0, "pos": (0.0, -40000.0, 0.0), "scale": (1.0, 1.0, 1.0),
+                                                                            "params": (79990.0, 0, 0, 0)}})),
+    Case("skip_stress128_nan_camera_32x18", 32, 18, prims=scenes.stress_primitives(128, seed=0x5EED0080),
+         setup=_stress_cam((float("nan"), 0.75, -14.0), floats={"_MaxSteps": 12.0})),
+    Case("skip_stress128_shadow_dir_128x72", 128, 72, kind="shadow_dir", setup=_shadow_dir, prims=scenes.stress_primitives(128, seed=0x5EED0080)),
+]
+BY_NAME.update({c.name: c for c in SKIP_CASES})
+
+
 def oracle_run(case: Case, O, threads: int = 0) -> dict:
     """binds the case on a fresh material and renders it with the CPU oracle"""
     with Material() as mat:
@@ -496,3 +549,51 @@ def random_case(seed: int) -> Case:
             mat.SetFloat("_RmDomainSize", dom_size)
 
     return Case(f"random_{seed}", w, h, setup=setup, prims=prims, src=use_src, sdepth=use_sd)
+
+
+def random_table_case(seed: int) -> Case:
+    """A seeded random plain smooth union of 65..256 primitives of all five kinds (the tables whose marches cull exactly):
+    dense or sparse placement, any rotation, scales in [.3, 2.3] (some unit, some identity rotations, sometimes the whole
+    table without rotation or scale), random camera looking at the origin from inside or outside the cloud, random march
+    uniforms, sometimes a source image / depth texture."""
+    rng = scenes.SplitMix64(0x7AB1E000 + seed)
+    u = rng.uniform
+    w, h = 24 + int(u() * 56), 16 + int(u() * 32)
+
+    def quat():
+        a = [u() * 2 - 1 for _ in range(4)]
+        n = math.sqrt(sum(x * x for x in a)) or 1.0
+        return [x / n for x in a]
+
+    n = 65 + int(u() * 192)
+    ext = [2.0 + u() * 18.0, 0.5 + u() * 6.0, 2.0 + u() * 18.0]
+    no_rot, no_scale = u() < 0.15, u() < 0.15
+    prims = []
+    for i in range(n):
+        t = int(u() * 5)
+        params = [(0.5 + u(),), (0.5 + u(), 0.5 + u(), 0.5 + u()), (0.3 + u(), 0.2 + 0.5 * u(), 0.05 + 0.1 * u()),
+                  (0.3 + 0.5 * u(), 0.3 + 0.5 * u()), (0.4 + 0.4 * u(), 0.1 + 0.2 * u())][t]
+        ident, unit = no_rot or u() < 0.2, no_scale or u() < 0.2
+        prims.append({"type": t, "op": 0, "pos": [float(F((u() * 2 - 1) * e)) for e in ext],
+                      "quat": [0.0, 0.0, 0.0, 1.0] if ident else [float(F(x)) for x in quat()],
+                      "scale": [1.0, 1.0, 1.0] if unit else [float(F(0.3 + 2.0 * u())) for _ in range(3)],
+                      "color": [float(F(0.25 + 0.75 * u())) for _ in range(3)], "params": params})
+    floats = {"_MaxSteps": float(int(20 + u() * 150)), "_MaxDist": float(F(15 + u() * 60)), "_StepFactor": float(F(0.3 + u() * 0.7)),
+              "_NormalSampleScale": float(F(10 ** (-5 + 3 * u())))}
+    az, el = u() * 2 * math.pi, (u() - 0.5) * 1.4
+    dist = (0.2 + u() * 1.8) * max(ext)
+    pos = np.array([dist * math.cos(el) * math.sin(az), dist * math.sin(el), -dist * math.cos(el) * math.cos(az)])
+    fov = 40 + u() * 60
+    light = [u() * 2 - 1, u(), u() * 2 - 1, 0.0]
+    use_src, use_sd = u() < 0.2, u() < 0.2
+
+    def setup(case, mat):
+        from raymarching_amd.unity import quat_look_rotation
+        cam = Camera(transform=Transform(position=pos.astype(F), rotation=quat_look_rotation(-pos)), fieldOfView=fov,
+                     aspect=case.w / case.h, nearClipPlane=0.3, farClipPlane=1000.0)
+        _base(mat, case.w, case.h, camera=cam)
+        mat.SetVector("_WorldSpaceLightPos0", np.asarray(light, dtype=F))
+        for k, v in floats.items():
+            mat.SetFloat(k, v)
+
+    return Case(f"random_table_{seed}", w, h, setup=setup, prims=prims, src=use_src, sdepth=use_sd)

@@ -30,7 +30,7 @@ def torch_cuda():
 KERNELS = {"tile": 1, "queue": 2, "stream": 3, "coop": 5}
 
 
-def gpu_run(case, torch, host_path=False, kernel=0, frames=1):
+def gpu_run(case, torch, host_path=False, kernel=0, frames=1, floats=None):
     """binds the case and renders it through the C ABI (device pointers unless host_path);
     `frames` > 1 re-renders into the same target (exercises the frame-to-frame tile history)"""
     from raymarching_amd import Graphics, Material, RenderTexture
@@ -38,6 +38,8 @@ def gpu_run(case, torch, host_path=False, kernel=0, frames=1):
     with Material() as mat:
         mat.set_kernel(kernel)
         src, sd = case.bind(mat)
+        for k, v in (floats or {}).items():
+            mat.SetFloat(k, v)
         if case.shadow:
             _bind_gpu_shadow_map(case, torch, mat)
         for _ in range(frames - 1):
@@ -144,6 +146,26 @@ def test_cooperative_table_kernel_equals_oracle(oracle, torch_cuda, name, kernel
     assert got["stats"]["n_hit"] == int(ref["hit"].sum()) == int(got["hit"].sum())
     assert got["stats"]["sum_steps_p"] == ref["stats"]["sum_steps_p"]
     assert got["stats"]["n_pixels"] == case.w * case.h
+
+
+@pytest.mark.parametrize("name", [c.name for c in cases.SKIP_CASES] + ["stress256_320x180", "stress100_160x90"])
+def test_exact_culling_in_table_marches_equals_oracle(oracle, torch_cuda, name):
+    """plain smooth unions of 65 to 256 primitives: the two marches skip the left subtrees of the smin tree whose value is
+    provably at least k above their right sibling's (smin then returns the right operand bit for bit); the frames and
+    counters are the oracle's, and the same with the full table walk (_RmTableSkip 0)"""
+    case = cases.BY_NAME[name]
+    ref = cases.oracle_run(case, oracle)
+    got = gpu_run(case, torch_cuda)
+    off = gpu_run(case, torch_cuda, floats={"_RmTableSkip": 0.0})
+    for g in (got, off):
+        if case.kind == "frag":
+            assert_frame_equal(g, ref, name)
+            assert g["stats"]["sum_steps_s"] == ref["stats"]["sum_steps_s"]
+        else:
+            assert np.array_equal(g["hit"], ref["hit"])
+            assert np.array_equal(g["depth"].view(np.uint32), ref["depth"].view(np.uint32))
+        assert g["stats"]["n_hit"] == int(ref["hit"].sum()) == int(g["hit"].sum())
+        assert g["stats"]["sum_steps_p"] == ref["stats"]["sum_steps_p"]
 
 
 @pytest.mark.parametrize("kernel,frames", [("tile", 1), ("queue", 1), ("queue", 4), ("stream", 2)])
@@ -422,6 +444,19 @@ def test_random_scenes(oracle, torch_cuda, seed, kernel):
     ref = cases.oracle_run(case, oracle)
     got = gpu_run(case, torch_cuda, kernel=KERNELS[kernel])
     assert_frame_equal(got, ref, case.name)
+    assert got["stats"]["sum_steps_p"] == ref["stats"]["sum_steps_p"]
+    assert got["stats"]["sum_steps_s"] == ref["stats"]["sum_steps_s"]
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_plain_tables_with_exact_culling(oracle, torch_cuda, seed):
+    """seeded random smooth unions of 65..256 primitives, the tables whose marches skip subtrees: bit-exact against the
+    oracle (automatic kernel choice)"""
+    case = cases.random_table_case(seed)
+    ref = cases.oracle_run(case, oracle)
+    got = gpu_run(case, torch_cuda)
+    assert_frame_equal(got, ref, case.name)
+    assert got["stats"]["n_hit"] == ref["stats"]["n_hit"]
     assert got["stats"]["sum_steps_p"] == ref["stats"]["sum_steps_p"]
     assert got["stats"]["sum_steps_s"] == ref["stats"]["sum_steps_s"]
 
