@@ -18,6 +18,10 @@ __global__ __launch_bounds__(256, 4) void rm_coop_kernelN_skip(const RmParams U)
     const SceneNCoop<ROT, SCL> coop = rm_make_coop_scene<ROT, SCL>(U, t, (RM_LDS float *)s_xw, (RM_LDS float *)s_x4, false);
     const int chunk = (1 << (32 - __builtin_clz((unsigned)U.n_prims - 1u))) >> 2;
     rmx::SceneNSkip<ROT, SCL> sc(coop, chunk);
+#ifdef RM_SKIP_STATS
+    __shared__ unsigned s_stat[8];
+    sc.st_lds = (RM_LDS unsigned *)s_stat;
+#endif
     unsigned c_hit = 0, c_p = 0, c_s = 0;
     const int x = blockIdx.x * 8 + (int)(lane & 7u), yl = blockIdx.y * 8 + (int)(lane >> 3);
     const bool in_bounds = x < U.w && yl < U.rows;
@@ -26,6 +30,9 @@ __global__ __launch_bounds__(256, 4) void rm_coop_kernelN_skip(const RmParams U)
     if (wv == 0) {
         if (in_bounds) rm_store_pixel(U, po);                             // the four waves hold the same pixels
         c_hit = rm_wave_sum(c_hit); c_p = rm_wave_sum(c_p); c_s = rm_wave_sum(c_s);
+#ifdef RM_SKIP_STATS           // the counters carry the statistics instead
+        c_hit = sc.st_max; c_p = sc.st_sum; c_s = sc.st_n;
+#endif
         const unsigned bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         if (lane < 3) U.partials[RM_SLOT_WORDS * bid + lane] = lane == 0 ? c_hit : lane == 1 ? c_p : c_s;
     }

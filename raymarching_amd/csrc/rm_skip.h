@@ -61,6 +61,11 @@ struct SceneNSkip {
     int groups;                    // leaves of the chunk / 4, a power of two
     unsigned long long all;        // one bit per leaf of the chunk
     unsigned long long mask;       // the leaves the next evaluation visits
+#ifdef RM_SKIP_STATS               // developer build: leaves visited by the slowest wave / by all four, per evaluation
+    mutable unsigned st_max = 0, st_sum = 0, st_n = 0, st_par = 0;
+    int st_phase = 0;              // 1 primary march, 2 shadow march
+    RM_LDS unsigned *st_lds = nullptr;
+#endif
 
     RM_DI SceneNSkip(const SceneNCoop<ROT, SCL> &c, int chunk) : coop(c) {
         cullable = c.part.n == chunk && chunk >= RM_SKIP_MIN_CHUNK && chunk <= RM_SKIP_MAX_CHUNK;
@@ -116,7 +121,9 @@ struct SceneNSkip {
         return coop.part.template leaf_w<false>(i, p, s, tw);
     }
     // group g of four leaves with the leaves m4 names (bit 3, the last leaf, is set whenever any is): an absent left
-    // operand leaves smin(left, right) = right.  (Fetching all four records up front whatever m4 says was measured: no gain.)
+    // operand leaves smin(left, right) = right.  Measured and dropped: fetching all four records up front whatever m4 says
+    // (no gain), one rolled loop over the present leaves (18 % slower: the four leaves of a full group overlap in the
+    // pipeline), straight-line code per pattern of present leaves (2 % slower).
     RM_DI float group(int g, unsigned m4, V3 p) const {
         const int i = g << 2;
         if (m4 == 15u) {
@@ -160,7 +167,19 @@ struct SceneNSkip {
         float mine = 0.0f;
         if (cullable) mine = walk(p);
         else if (coop.part.n > 0) mine = coop.part.w(p);
+#ifdef RM_SKIP_STATS
+        if (coop.lane == 0) st_lds[st_par * 4u + coop.wv] = (unsigned)__builtin_popcountll(mask);
+        const float r = coop.finish(mine);                 // has the barrier
+        if (st_phase == RM_SKIP_STATS) {
+            const unsigned a = st_lds[st_par * 4u], b = st_lds[st_par * 4u + 1u], c = st_lds[st_par * 4u + 2u], d = st_lds[st_par * 4u + 3u];
+            const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+            st_max += ab > cd ? ab : cd; st_sum += a + b + c + d; st_n++;
+        }
+        st_par ^= 1u;
+        return r;
+#else
         return coop.finish(mine);
+#endif
     }
 };
 
@@ -181,6 +200,9 @@ RM_DI PixelOut compute_pixel(const RmParams &U, SKIP &sc, const STRICT &strict, 
     bool active = in_bounds && U.n_steps > 0;
     float dm = 0.0f, adts = __builtin_inff(), contact = 0.0f;
     unsigned evals = 0;
+#ifdef RM_SKIP_STATS
+    sc.st_phase = 1;
+#endif
     for (int i = 0; i < U.n_steps; i++) {
         if (!__any(active)) break;
         const V3 cp = mk3(ro.x + rd.x * dm, ro.y + rd.y * dm, ro.z + rd.z * dm);
@@ -220,6 +242,9 @@ RM_DI PixelOut compute_pixel(const RmParams &U, SKIP &sc, const STRICT &strict, 
         bool sactive = hit && U.n_steps > 0;
         float sdm = 0.0f, res = 1.0f;
         unsigned sev = 0;
+#ifdef RM_SKIP_STATS
+        sc.st_phase = 2;
+#endif
         for (int i = 0; i < U.n_steps; i++) {
             if (!__any(sactive)) break;
             const V3 cp = mk3(p.x + L.x * sdm, p.y + L.y * sdm, p.z + L.z * sdm);

@@ -75,6 +75,22 @@ def main():
                 cc = [np.full(1, v, dtype=f) for v in ctr]
                 LB = np.array([float(sc.prim(p, cc[0], cc[1], cc[2])[0]) for p in sc.prims]) - hd - 0.01
 
+            # optional: the marching lanes in clusters (rows of the tile), one box each; a block is skipped only if every
+            # cluster allows it (the union of the clusters' masks is still exact)
+            NCL = int(os.environ.get("CLUSTERS", "1"))
+            if NCL > 1:
+                lanes = np.nonzero(a)[0]
+                cl = [lanes[(lanes // 8) * NCL // 8 == c] for c in range(NCL)]
+                LBs, HDs = [], []
+                for L_ in cl:
+                    if len(L_) == 0:
+                        continue
+                    qq = np.stack([px[L_], py[L_], pz[L_]], 1).astype(np.float64)
+                    lo_, hi_ = qq.min(0), qq.max(0)
+                    c_, h_ = .5 * (lo_ + hi_), .5 * np.linalg.norm(hi_ - lo_)
+                    cc = [np.full(1, v, dtype=f) for v in c_]
+                    LBs.append(np.array([float(sc.prim(p, cc[0], cc[1], cc[2])[0]) for p in sc.prims]) - h_ - 0.01)
+                    HDs.append(h_)
             visited = [0]
 
             def ev(lo_i, hi_i):
@@ -86,7 +102,9 @@ def main():
                 vb = ev(mid, hi_i)
                 lvl = int(math.log2(mid - lo_i))
                 lbl = LB[lo_i:mid].min() - 0.126 * lvl
-                if STATIC:
+                if STATIC and NCL > 1:
+                    ok = all((lb_[mid:hi_i].min() + 2 * h_ + 0.02) + 0.5 <= lb_[lo_i:mid].min() - 0.126 * lvl for lb_, h_ in zip(LBs, HDs))
+                elif STATIC:
                     ok = (LB[mid:hi_i].min() + 2 * hd + 0.02) + 0.5 <= lbl          # upper bound of the right operand known beforehand
                 else:
                     ok = np.all(vb + f(0.5) <= lbl)

@@ -29,4 +29,4 @@ with Material() as mat:
         step()
     e1.record(); torch.cuda.synchronize()
     import hashlib
-    print(f"{e0.elapsed_time(e1) / 3:.2f} ms  sha {hashlib.sha256(rt.color.cpu().numpy().tobytes()).hexdigest()[:12]} {mat.stats()['sum_steps_s']}")
+    print(f"{e0.elapsed_time(e1) / 3:.2f} ms  sha {hashlib.sha256(rt.color.cpu().numpy().tobytes()).hexdigest()[:12]} {mat.stats()}")
