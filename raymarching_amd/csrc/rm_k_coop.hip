@@ -12,8 +12,15 @@ namespace {
 
 // CSG: the table carries op bits.  Kept apart so that the plain-union kernel, which is the one the big tables of the
 // benchmark use, does not carry the smax paths in its register budget (both fit 4 waves per SIMD).
+// Waves per SIMD the register allocator is asked to fit.  A block's four waves meet at a barrier per evaluation, so a wave
+// often waits for its slowest sibling; a fifth resident block covers that wait (stress scene 34.0 -> 31.1 ms, 128
+// primitives 14.9 -> 13.8 ms) at the price of a few dwords of scratch outside the table walk.  With op bits the fifth block
+// would cost over 100 bytes of scratch: those stay at four.
+#ifndef RM_COOP_WAVES
+#define RM_COOP_WAVES 5
+#endif
 template <bool ROT, int SCL, bool CSG>
-__global__ __launch_bounds__(256, 4) void rm_coop_kernelN(const RmParams U) {
+__global__ __launch_bounds__(256, CSG ? 4 : RM_COOP_WAVES) void rm_coop_kernelN(const RmParams U) {
     __shared__ float s_xw[2 * 4 * 64];
     __shared__ float s_x4[4 * 4 * 64];
     PrimTable<true> t;

@@ -8,8 +8,11 @@
 
 namespace {
 
+#ifndef RM_SKIP_WAVES
+#define RM_SKIP_WAVES 5
+#endif
 template <bool ROT, int SCL>
-__global__ __launch_bounds__(256, 4) void rm_coop_kernelN_skip(const RmParams U) {
+__global__ __launch_bounds__(256, RM_SKIP_WAVES) void rm_coop_kernelN_skip(const RmParams U) {
     __shared__ float s_xw[2 * 4 * 64];
     __shared__ float s_x4[4 * 4 * 64];
     PrimTable<true> t;

@@ -49,7 +49,7 @@ def kernel_resources(lib: str):
 def short_name(mangled: str) -> str:
     """rm_queue_kernel4<rot=1, scl=1> from _ZN12_GLOBAL__N_116rm_queue_kernel4ILb1ELi1EEEv8RmParams; further template
     arguments are appended as they are (rm_coop_kernelN<rot=1, scl=1, 0>)"""
-    m = re.search(r"\d+(rm_[a-z_]+[4NF]?(?:_fx|_fast|_cull|_coop|_plain)?)(?:I((?:L[bi]\d+E)+)E)?", mangled)
+    m = re.search(r"\d+(rm_[a-z_]+[4NF]?(?:_fx|_fast|_cull|_coop|_plain|_skip)?)(?:I((?:L[bi]\d+E)+)E)?", mangled)
     if not m:
         return mangled
     if m.group(2) is None:
@@ -61,7 +61,7 @@ def short_name(mangled: str) -> str:
 
 def short_name_from_demangled(name: str) -> str:
     """rm_queue_kernel4<rot=0, scl=0> from 'void (anonymous namespace)::rm_queue_kernel4<false, 0>(RmParams)'"""
-    m = re.search(r"(rm_[a-z_]+[4NF]?(?:_fx|_fast|_cull|_coop|_plain)?)(?:<([^>]*)>)?", name)
+    m = re.search(r"(rm_[a-z_]+[4NF]?(?:_fx|_fast|_cull|_coop|_plain|_skip)?)(?:<([^>]*)>)?", name)
     if not m:
         return name
     if m.group(2) is None:
