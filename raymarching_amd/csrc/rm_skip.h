@@ -42,7 +42,9 @@ template <bool MAX> RM_DI float wave_reduce(float v) {
 
 #define RM_SKIP_LEVELS 5          // levels of the stack over groups of four leaves: chunks of up to 64 leaves
 #define RM_SKIP_MAX_CHUNK 64      // one threshold per lane
-#define RM_SKIP_MIN_CHUNK 32
+#ifndef RM_SKIP_MIN_CHUNK
+#define RM_SKIP_MIN_CHUNK 16      // quarters of 16 leaves (33 to 64 primitives) still gain 3-14 %
+#endif
 #define RM_SKIP_RANGE 1000.0f     // coordinates and distances beyond this: no culling (the margin below is sized for it)
 
 // the record of leaf i as this lane's own (lanes read different records; PrimTable::get is for wave-uniform indices)
@@ -74,8 +76,9 @@ struct SceneNSkip {
         mask = all;
     }
 
-    // Every lane of the wave calls this; `active` lanes evaluate the scene at q next.
-    RM_DI void prepare(bool active, V3 q) {
+    // Every lane of the wave calls this; `active` lanes evaluate the scene next, at q or anywhere within `grow` of q along
+    // each axis.
+    RM_DI void prepare(bool active, V3 q, float grow = 0.0f) {
         mask = all;
         if (!cullable || !__any(active)) return;
         const float inf = __builtin_inff();
@@ -85,7 +88,8 @@ struct SceneNSkip {
         const float cx = 0.5f * (lox + hix), cy = 0.5f * (loy + hiy), cz = 0.5f * (loz + hiz);
         const float ex = hix - lox, ey = hiy - loy, ez = hiz - loz;
         // every marching sample point is within hd of the centre (rounded up), .01 for the rounding of the evaluations
-        const float hd = 0.5f * __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez) * 1.0001f + 1e-5f * (fabsf(cx) + fabsf(cy) + fabsf(cz)) + 0.01f;
+        const float hd = 0.5f * __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez) * 1.0001f + 1e-5f * (fabsf(cx) + fabsf(cy) + fabsf(cz)) + 0.01f +
+                         1.7321f * grow;
         const int j = (int)coop.lane;
         const bool mine = j < 4 * groups;
         float lb = inf, ub = inf;
@@ -183,7 +187,13 @@ struct SceneNSkip {
     }
 };
 
-// The fragment program for one pixel with the two marches on the culled evaluation.  Every lane of the wave calls this
+// the culled evaluation under the name the normal taps call
+template <class SKIP> struct Taps {
+    const SKIP &sc;
+    RM_DI float w(V3 p) const { return sc.eval(p); }
+};
+
+// The fragment program for one pixel with the two marches and the six normal taps on the culled evaluation.  Every lane of the wave calls this
 // (lanes outside the frame with in_bounds = false and the coordinates of some pixel inside): the bounds are built by the
 // whole wave.  Operations and their order are those of rm_compute_pixel.
 template <class SKIP, class STRICT>
@@ -226,15 +236,20 @@ RM_DI PixelOut compute_pixel(const RmParams &U, SKIP &sc, const STRICT &strict, 
 
     if (U.mode == RM_MODE_FRAG) {
         const V3 L = mk3(rm_vgpr(U.light[0]), rm_vgpr(U.light[1]), rm_vgpr(U.light[2]));
-        // ---- normal, colour: the whole table (shader:63-67, 193) ----
+        // ---- normal: six taps within _NormalSampleScale of the hit point, one set of bounds for all of them
+        // (shader:63-67); colour: the whole table (shader:193) ----
         const V3 hp = mk3(ro.x + rd.x * dm, ro.y + rd.y * dm, ro.z + rd.z * dm);
         V3 n = mk3(0.0f, 0.0f, 0.0f), raw = n;
         V4 s;
         s.x = s.y = s.z = s.w = 0.0f;
-        if (hit) {
-            raw = rm_normal_raw(U, strict, hp);
-            n = rm_normalize(raw);
-            s = strict.full(hp);
+        if (__any(hit)) {
+            sc.prepare(hit, hp, U.nss);
+            const V3 taps = rm_normal_raw(U, Taps<SKIP>{sc}, hp);
+            if (hit) {
+                raw = taps;
+                n = rm_normalize(raw);
+                s = strict.full(hp);
+            }
         }
         // ---- getshadow (shader:102-123), hit lanes only ----
         const float c0 = contact;

@@ -403,7 +403,7 @@ def _edited(prims, edits):
     return out
 
 
-# Plain smooth-union tables of 65 to 256 primitives take the shared-tile kernel with exact culling in the marches: table
+# Plain smooth-union tables of 33 to 256 primitives take the shared-tile kernel with exact culling in the marches: table
 # sizes that give full, partial and one-leaf quarters, the variants without rotation / scale, a camera inside the slab, the
 # guards (coordinates beyond the range the rounding margin is sized for, a negative and a zero scale, an enormous
 # primitive, a camera that is not a number) and a depth pass.  Compared with the oracle on the GPU only (no golden entry).
@@ -552,7 +552,7 @@ def random_case(seed: int) -> Case:
 
 
 def random_table_case(seed: int) -> Case:
-    """A seeded random plain smooth union of 65..256 primitives of all five kinds (the tables whose marches cull exactly):
+    """A seeded random plain smooth union of 33..256 primitives of all five kinds (the tables whose marches cull exactly):
     dense or sparse placement, any rotation, scales in [.3, 2.3] (some unit, some identity rotations, sometimes the whole
     table without rotation or scale), random camera looking at the origin from inside or outside the cloud, random march
     uniforms, sometimes a source image / depth texture."""
