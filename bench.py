@@ -341,6 +341,34 @@ def run_single(args) -> None:
                                    "ms_per_step": el / n_orb_steps * 1e3, "Mrays_per_s": tot_rays / el / 1e6,
                                    "tflops": tot_fl / (ms * n_orb_steps * 1e-3) / 1e12,
                                    "frac_of_peak": tot_fl / (ms * n_orb_steps * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS}
+        # ---- a camera that moves as cameras do: half a degree of the orbit per frame ---------------------------------
+        n_fine, per_turn = 48, 720
+        fine = []
+        for k in range(n_fine):
+            r = Raymarching(scenes.orbit_camera(k, per_turn, w, h), mat, scenes.default_transforms())
+            fine.append((np.ascontiguousarray(r.GetFrustumCorners().m, dtype=np.float32),
+                         np.ascontiguousarray(r.cam.cameraToWorldMatrix.m, dtype=np.float32),
+                         np.ascontiguousarray(np.append(r.cam.transform.position, 0.0), dtype=np.float32)))
+        fine_rays, fine_flops = 0, 0.0
+
+        def step_fine(i):
+            fc, c2w, p4 = fine[i % n_fine]
+            lib.rm_set_matrix(ctx, b"_FrustrumCorners", _fp(fc))
+            lib.rm_set_matrix(ctx, b"_CameraInvViewMatrix", _fp(c2w))
+            lib.rm_set_vector(ctx, b"_WorldSpaceCameraPos", _fp(p4))
+            step(i)
+
+        for k in range(n_fine):
+            step_fine(k)
+            s2 = mat.stats()
+            fine_rays += rays(s2); fine_flops += algorithmic_flops(s2)
+        el, ms = timed(torch, step_fine, n_fine, n_fine, ramp_s=RAMP_S)
+        sec["smooth_camera_4k"] = {"what": f"{w}x{h}, {n_fine} consecutive poses of an orbit in half-degree steps (SetMatrix x2 + SetVector + "
+                                           "Blit per step): the tile queue is ordered by the previous frame's costs, and a long tile also "
+                                           "lists its eight neighbours",
+                                   "ms_per_step": el / n_fine * 1e3, "Mrays_per_s": fine_rays / el / 1e6,
+                                   "tflops": fine_flops / (ms * n_fine * 1e-3) / 1e12,
+                                   "frac_of_peak": fine_flops / (ms * n_fine * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS}
         mat.close()
 
         # ---- 1920x1080 ------------------------------------------------------------------------------------------

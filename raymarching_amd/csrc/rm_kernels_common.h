@@ -20,6 +20,11 @@
 #ifndef RM_HEAVY_PRIO
 #define RM_HEAVY_PRIO 3
 #endif
+// a tile whose cost is this many times the heavy threshold also puts its eight neighbours on the next frame's heavy list
+// (0: never)
+#ifndef RM_HEAVY_DILATE
+#define RM_HEAVY_DILATE 2
+#endif
 // words per block in the counter-slot buffer; a timeline build (developer tool) appends
 // start/end timestamps of the block (100 MHz s_memrealtime) and its hardware id
 #ifdef RM_TIMELINE
@@ -645,10 +650,41 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
 #ifdef RM_TIMELINE
             n_done++; max_cost = max_cost > cost ? max_cost : cost;
 #endif
+#if RM_HEAVY_DILATE
+            // A camera that moves carries a long tile into a neighbouring one by the next frame: a tile well above the
+            // threshold also lists its eight neighbours (lane k < 9 takes neighbour k; the bitmap's test-and-set keeps a tile
+            // from being listed twice, which would render it twice).
+            if (cost >= Q.heavy_threshold) {
+                const bool spread = cost >= RM_HEAVY_DILATE * Q.heavy_threshold;
+                bool add = false;
+                unsigned nt = tile;
+                if (lane < 9 && (spread || lane == 4)) {
+                    const unsigned per_pose = Q.tiles_x * Q.tiles_y, base = tile - tile % per_pose, t2 = tile - base;
+                    const int ty = (int)(t2 / Q.tiles_x), tx = (int)(t2 - (unsigned)ty * Q.tiles_x);
+                    const int nx = tx + lane % 3 - 1, ny = ty + lane / 3 - 1;
+                    if (nx >= 0 && ny >= 0 && nx < (int)Q.tiles_x && ny < (int)Q.tiles_y) {
+                        nt = base + (unsigned)ny * Q.tiles_x + (unsigned)nx;
+                        const unsigned bit = 1u << (nt & 31);
+                        add = !(atomicOr(&bitmap_nxt[nt >> 5], bit) & bit);
+                    }
+                }
+                const unsigned long long am = __ballot(add);
+                if (am) {
+                    unsigned idx = 0;
+                    if (lane == 0) idx = atomicAdd(&Q.heavy_count[Q.hv_nxt], (unsigned)__builtin_popcountll(am));
+                    idx = __builtin_amdgcn_readfirstlane(idx) + (unsigned)__builtin_popcountll(am & ((1ull << lane) - 1ull));
+                    if (add) {
+                        if (idx < Q.heavy_cap) heavy_nxt[idx] = nt;
+                        else atomicAnd(&bitmap_nxt[nt >> 5], ~(1u << (nt & 31)));      // no room on the list: it stays in image order
+                    }
+                }
+            }
+#else
             if (cost >= Q.heavy_threshold && lane == 0) {
                 unsigned idx = atomicAdd(&Q.heavy_count[Q.hv_nxt], 1u);
                 if (idx < Q.heavy_cap) { heavy_nxt[idx] = tile; atomicOr(&bitmap_nxt[tile >> 5], 1u << (tile & 31)); }
             }
+#endif
         }
         cur = nxt;
     }

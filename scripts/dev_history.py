@@ -57,3 +57,23 @@ print(f"(b) poses in turn, stale prediction:      {t:.1f} us per frame", flush=T
 mat.SetFloat("_RmTileFeedback", 0.0)
 t = timed(lambda i: (set_pose(i % n_orbit), blit()), n_orbit * 4)
 print(f"(c) poses in turn, no ordering:           {t:.1f} us per frame", flush=True)
+
+# (d)-(f): a camera that moves as cameras do, half a degree of the orbit per frame (720 poses per turn), 96 consecutive frames
+mat.SetFloat("_RmTileFeedback", 1.0)
+n_fine, per_turn = 96, 720
+cams = [Raymarching(scenes.orbit_camera(k, per_turn, w, h), mat, scenes.default_transforms()) for k in range(n_fine)]
+arr = [(np.ascontiguousarray(r.GetFrustumCorners().m, dtype=np.float32)[None], np.ascontiguousarray(r.cam.cameraToWorldMatrix.m, dtype=np.float32)[None],
+        np.ascontiguousarray(r.cam.transform.position, dtype=np.float32)[None]) for r in cams]
+pos4 = [np.ascontiguousarray(np.append(a[2][0], 0.0), dtype=np.float32) for a in arr]
+tot = 0.0
+for i in range(n_fine):
+    set_pose(i)
+    blit(); blit()
+    tot += timed(lambda _i: blit(), 8)
+print(f"(d) half-degree steps, each pose repeated (exact prediction): {tot / n_fine:.1f} us per frame", flush=True)
+set_pose(0); blit()
+t = timed(lambda i: (set_pose(i % n_fine), blit()), n_fine * 3)
+print(f"(e) half-degree steps in turn (prediction one frame old):     {t:.1f} us per frame", flush=True)
+mat.SetFloat("_RmTileFeedback", 0.0)
+t = timed(lambda i: (set_pose(i % n_fine), blit()), n_fine * 3)
+print(f"(f) half-degree steps in turn, no ordering:                   {t:.1f} us per frame", flush=True)
