@@ -16,6 +16,8 @@ while [ $# -ge 2 ]; do
   done
   wait
   /opt/rocm/bin/hipcc $FLAGS $defs -c rm_api.cpp -o ../variants/a_$tag.o; api=../variants/a_$tag.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/librmhip_$tag.so $objs $api && echo built $tag
+  # the other translation units come from the main build as they are
+  others=$(ls rm_k_*.o rm_scratch.o | grep -v -e "^rm_k_tile.o$" -e "^rm_k_tile_fx.o$" -e "^rm_k_queue.o$" -e "^rm_k_stream.o$" | tr '\n' ' ')
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/librmhip_$tag.so $objs $others $api && echo built $tag
   rm -f $objs
 done
