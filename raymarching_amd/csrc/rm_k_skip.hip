@@ -56,7 +56,7 @@ bool rm_skip_applies(const RmParams &U) {
     return chunk >= RM_SKIP_MIN_CHUNK && chunk <= RM_SKIP_MAX_CHUNK;
 }
 
-// plain smooth-union tables staged whole in LDS whose quarter is 16 to 64 primitives (33 to 256 primitives); same grid and
+// plain smooth-union tables staged whole in LDS whose quarter is 16 to 128 primitives (33 to 512 primitives); same grid and
 // counter slots as rm_launch_coop_tiles
 hipError_t rm_launch_coop_skip_tiles(const RmParams &U, hipStream_t stream) {
     if (U.w <= 0 || U.rows <= 0 || U.n_poses <= 0 || !rm_skip_applies(U)) return hipErrorInvalidValue;

@@ -40,8 +40,8 @@ template <bool MAX> RM_DI float wave_reduce(float v) {
     return MAX ? fmaxf(fmaxf(a, b), fmaxf(c, d)) : fminf(fminf(a, b), fminf(c, d));
 }
 
-#define RM_SKIP_LEVELS 5          // levels of the stack over groups of four leaves: chunks of up to 64 leaves
-#define RM_SKIP_MAX_CHUNK 64      // one threshold per lane
+#define RM_SKIP_LEVELS 6          // levels of the stack over groups of four leaves: chunks of up to 128 leaves
+#define RM_SKIP_MAX_CHUNK 128     // two leaves per lane in the bounds, two mask words
 #ifndef RM_SKIP_MIN_CHUNK
 #define RM_SKIP_MIN_CHUNK 16      // quarters of 16 leaves (33 to 64 primitives) still gain 3-14 %
 #endif
@@ -61,8 +61,8 @@ struct SceneNSkip {
     const SceneNCoop<ROT, SCL> &coop;
     bool cullable;                 // this wave's chunk is complete and has RM_SKIP_MIN_CHUNK..RM_SKIP_MAX_CHUNK leaves
     int groups;                    // leaves of the chunk / 4, a power of two
-    unsigned long long all;        // one bit per leaf of the chunk
-    unsigned long long mask;       // the leaves the next evaluation visits
+    unsigned long long all[2];     // one bit per leaf of the chunk
+    unsigned long long mask[2];    // the leaves the next evaluation visits
 #ifdef RM_SKIP_STATS               // developer build: leaves visited by the slowest wave / by all four, per evaluation
     mutable unsigned st_max = 0, st_sum = 0, st_n = 0, st_par = 0;
     int st_phase = 0;              // 1 primary march, 2 shadow march
@@ -72,14 +72,15 @@ struct SceneNSkip {
     RM_DI SceneNSkip(const SceneNCoop<ROT, SCL> &c, int chunk) : coop(c) {
         cullable = c.part.n == chunk && chunk >= RM_SKIP_MIN_CHUNK && chunk <= RM_SKIP_MAX_CHUNK;
         groups = chunk >> 2;
-        all = chunk >= 64 ? ~0ull : ((1ull << chunk) - 1ull);
-        mask = all;
+        all[0] = chunk >= 64 ? ~0ull : ((1ull << chunk) - 1ull);
+        all[1] = chunk > 64 ? ~0ull : 0ull;
+        mask[0] = all[0]; mask[1] = all[1];
     }
 
     // Every lane of the wave calls this; `active` lanes evaluate the scene next, at q or anywhere within `grow` of q along
     // each axis.
     RM_DI void prepare(bool active, V3 q, float grow = 0.0f) {
-        mask = all;
+        mask[0] = all[0]; mask[1] = all[1];
         if (!cullable || !__any(active)) return;
         const float inf = __builtin_inff();
         const float lox = wave_reduce<false>(active ? q.x : inf), hix = wave_reduce<true>(active ? q.x : -inf);
@@ -91,31 +92,47 @@ struct SceneNSkip {
         const float hd = 0.5f * __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez) * 1.0001f + 1e-5f * (fabsf(cx) + fabsf(cy) + fabsf(cz)) + 0.01f +
                          1.7321f * grow;
         const int j = (int)coop.lane;
-        const bool mine = j < 4 * groups;
-        float lb = inf, ub = inf;
+        const int n_leaves = 4 * groups, halves = n_leaves > 64 ? 2 : 1;
         bool bad = !(fabsf(cx) + fabsf(cy) + fabsf(cz) + hd <= RM_SKIP_RANGE);          // also true for NaN
-        if (mine) {
-            const RmPrimDev P = lane_record(coop.part.tab.T, j);
-            const float d = rm_prim_typed<ROT, SCL>(P, P.type & RM_TYPE_MASK, mk3(cx, cy, cz), coop.part.tiny);
-            // (a negative scale would make min(scale) the largest in magnitude and the leaf steeper than 1)
-            bad = bad || !(fabsf(d) + hd <= RM_SKIP_RANGE) || !(fabsf(P.px) + fabsf(P.py) + fabsf(P.pz) <= RM_SKIP_RANGE) ||
-                  (SCL != RM_SCL_UNIT && !(P.ms > 0.0f));
-            lb = d - hd;
-            ub = d + hd;
+        unsigned long long keep[2] = {0ull, 0ull};
+        float lb_half0 = inf;           // lower bound of leaves 0..63 as a block (chunks of 128)
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {
+            if (hf >= halves) break;
+            const bool mine = 64 * hf + j < n_leaves;
+            float lb = inf, ub = inf;
+            if (mine) {
+                const RmPrimDev P = lane_record(coop.part.tab.T, 64 * hf + j);
+                const float d = rm_prim_typed<ROT, SCL>(P, P.type & RM_TYPE_MASK, mk3(cx, cy, cz), coop.part.tiny);
+                // (a negative scale would make min(scale) the largest in magnitude and the leaf steeper than 1)
+                bad = bad || !(fabsf(d) + hd <= RM_SKIP_RANGE) || !(fabsf(P.px) + fabsf(P.py) + fabsf(P.pz) <= RM_SKIP_RANGE) ||
+                      (SCL != RM_SCL_UNIT && !(P.ms > 0.0f));
+                lb = d - hd;
+                ub = d + hd;
+            }
+            // level l: the aligned blocks of 2^l leaves meet their siblings; a left block (bit l of j clear) is skipped if the
+            // right one's upper bound is .5 below its lower bound, which loses .126 per level of smin inside it
+            bool skip = false;
+#pragma unroll
+            for (int l = 0; l < 6; l++) {
+                const float sub = __shfl_xor(ub, 1 << l), slb = __shfl_xor(lb, 1 << l);
+                skip = skip || (!((j >> l) & 1) && sub + (0.5f + 0.126f * (float)l) <= lb);
+                ub = fminf(ub, sub);
+                lb = fminf(lb, slb);
+            }
+            // (after the butterfly lb and ub are those of all 64 leaves of this half, in every lane)
+            const unsigned long long k = __ballot(mine && !skip);
+            if (hf == 0) {
+                lb_half0 = lb;
+                keep[0] = k;
+            } else {
+                keep[1] = k;
+                if (__all(ub + (0.5f + 0.126f * 6.0f) <= lb_half0)) keep[0] = 0ull;      // the first half as a block against the second
+            }
         }
         if (__any(bad)) return;
 #ifndef RM_SKIP_NEVER
-        // level l: the aligned blocks of 2^l leaves meet their siblings; a left block (bit l of j clear) is skipped if the
-        // right one's upper bound is .5 below its lower bound, which loses .126 per level of smin inside it
-        bool skip = false;
-#pragma unroll
-        for (int l = 0; l < 6; l++) {
-            const float sub = __shfl_xor(ub, 1 << l), slb = __shfl_xor(lb, 1 << l);
-            skip = skip || (!((j >> l) & 1) && sub + (0.5f + 0.126f * (float)l) <= lb);
-            ub = fminf(ub, sub);
-            lb = fminf(lb, slb);
-        }
-        mask = __ballot(mine && !skip);
+        mask[0] = keep[0]; mask[1] = keep[1];
 #endif
     }
 
@@ -149,7 +166,7 @@ struct SceneNSkip {
         unsigned pres = 0;                                      // bit l: st[l] holds a subtree (else it was skipped)
         float v = 0.0f;
         for (int g = 0; g < groups; g++) {
-            const unsigned m4 = (unsigned)(mask >> (4 * g)) & 15u;
+            const unsigned m4 = (unsigned)((g < 16 ? mask[0] : mask[1]) >> (4 * (g & 15))) & 15u;
             const int merges = __builtin_ctz(~(unsigned)g);     // trailing ones of g = finished lower levels
             const unsigned below = (1u << merges) - 1u;
             if (m4 == 0u) {                                     // a skipped block is a whole left operand: nothing below it is kept
@@ -172,7 +189,7 @@ struct SceneNSkip {
         if (cullable) mine = walk(p);
         else if (coop.part.n > 0) mine = coop.part.w(p);
 #ifdef RM_SKIP_STATS
-        if (coop.lane == 0) st_lds[st_par * 4u + coop.wv] = (unsigned)__builtin_popcountll(mask);
+        if (coop.lane == 0) st_lds[st_par * 4u + coop.wv] = (unsigned)(__builtin_popcountll(mask[0]) + __builtin_popcountll(mask[1]));
         const float r = coop.finish(mine);                 // has the barrier
         if (st_phase == RM_SKIP_STATS) {
             const unsigned a = st_lds[st_par * 4u], b = st_lds[st_par * 4u + 1u], c = st_lds[st_par * 4u + 2u], d = st_lds[st_par * 4u + 3u];

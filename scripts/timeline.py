@@ -38,3 +38,8 @@ resident = [(int(((st <= t) & (en > t)).sum())) for t in edges]
 print("resident blocks every 5 us:", resident)
 started = [int((st <= t).sum()) for t in edges]
 print("started blocks every 5 us:", started)
+late = np.argsort(en)[::-1][:12]
+print("the waves that end last: (end us, tiles done, longest tile in evaluations, started on a heavy tile)")
+nh = int(os.environ.get("RM_NHEAVY", "0"))
+for b in late:
+    print("   %6.1f  %3d  %4d" % (en[b], s[b, 7] & 0xffff, s[b, 7] >> 16))

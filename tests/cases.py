@@ -403,7 +403,7 @@ def _edited(prims, edits):
     return out
 
 
-# Plain smooth-union tables of 33 to 256 primitives take the shared-tile kernel with exact culling in the marches: table
+# Plain smooth-union tables of 33 to 512 primitives take the shared-tile kernel with exact culling in the marches: table
 # sizes that give full, partial and one-leaf quarters, the variants without rotation / scale, a camera inside the slab, the
 # guards (coordinates beyond the range the rounding margin is sized for, a negative and a zero scale, an enormous
 # primitive, a camera that is not a number) and a depth pass.  Compared with the oracle on the GPU only (no golden entry).
@@ -411,6 +411,11 @@ SKIP_CASES = [
     Case("skip_stress65_160x90", 160, 90, setup=_stress, prims=scenes.stress_primitives(65, seed=0x5EED0041)),
     Case("skip_stress128_160x90", 160, 90, setup=_stress, prims=scenes.stress_primitives(128, seed=0x5EED0080)),
     Case("skip_stress200_160x90", 160, 90, setup=_stress, prims=scenes.stress_primitives(200, seed=0x5EED00C8)),
+    # quarters of 128 leaves: two leaves per lane in the bounds, two mask words (257: 128, 128 and a single leaf)
+    Case("skip_stress257_128x72", 128, 72, setup=_stress, prims=scenes.stress_primitives(257, seed=0x5EED0101)),
+    Case("skip_stress300_128x72", 128, 72, setup=_stress, prims=scenes.stress_primitives(300, seed=0x5EED012C)),
+    Case("skip_stress512_128x72", 128, 72, setup=_stress, prims=scenes.stress_primitives(512, seed=0x5EED0200)),
+    Case("skip_stress512_inside_96x54", 96, 54, setup=_stress_cam((0.3, 0.1, -2.0), (0.0, 25.0, 0.0)), prims=scenes.stress_primitives(512, seed=0x5EED0200)),
     Case("skip_stress256_inside_160x90", 160, 90, setup=_stress_cam((0.3, 0.1, -2.0), (0.0, 25.0, 0.0)), prims=scenes.stress_primitives(256)),
     Case("skip_stress256_above_128x72", 128, 72, setup=_stress_cam((0.0, 9.0, 0.0), (88.0, 0.0, 0.0)), prims=scenes.stress_primitives(256)),
     Case("skip_stress128_far_camera_96x54", 96, 54, prims=scenes.stress_primitives(128, seed=0x5EED0080),
@@ -552,7 +557,7 @@ def random_case(seed: int) -> Case:
 
 
 def random_table_case(seed: int) -> Case:
-    """A seeded random plain smooth union of 33..256 primitives of all five kinds (the tables whose marches cull exactly):
+    """A seeded random plain smooth union of 33..512 primitives of all five kinds (the tables whose marches cull exactly):
     dense or sparse placement, any rotation, scales in [.3, 2.3] (some unit, some identity rotations, sometimes the whole
     table without rotation or scale), random camera looking at the origin from inside or outside the cloud, random march
     uniforms, sometimes a source image / depth texture."""
@@ -565,7 +570,7 @@ def random_table_case(seed: int) -> Case:
         n = math.sqrt(sum(x * x for x in a)) or 1.0
         return [x / n for x in a]
 
-    n = 65 + int(u() * 192)
+    n = 33 + int(u() * 480)
     ext = [2.0 + u() * 18.0, 0.5 + u() * 6.0, 2.0 + u() * 18.0]
     no_rot, no_scale = u() < 0.15, u() < 0.15
     prims = []

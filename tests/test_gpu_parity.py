@@ -150,7 +150,7 @@ def test_cooperative_table_kernel_equals_oracle(oracle, torch_cuda, name, kernel
 
 @pytest.mark.parametrize("name", [c.name for c in cases.SKIP_CASES] + ["stress256_320x180", "stress100_160x90"])
 def test_exact_culling_in_table_marches_equals_oracle(oracle, torch_cuda, name):
-    """plain smooth unions of 33 to 256 primitives: the two marches skip the left subtrees of the smin tree whose value is
+    """plain smooth unions of 33 to 512 primitives: the two marches skip the left subtrees of the smin tree whose value is
     provably at least k above their right sibling's (smin then returns the right operand bit for bit); the frames and
     counters are the oracle's, and the same with the full table walk (_RmTableSkip 0)"""
     case = cases.BY_NAME[name]
@@ -450,7 +450,7 @@ def test_random_scenes(oracle, torch_cuda, seed, kernel):
 
 @pytest.mark.parametrize("seed", range(40))
 def test_random_plain_tables_with_exact_culling(oracle, torch_cuda, seed):
-    """seeded random smooth unions of 33..256 primitives, the tables whose marches skip subtrees: bit-exact against the
+    """seeded random smooth unions of 33..512 primitives, the tables whose marches skip subtrees: bit-exact against the
     oracle (automatic kernel choice)"""
     case = cases.random_table_case(seed)
     ref = cases.oracle_run(case, oracle)
