@@ -11,7 +11,7 @@ namespace {
 #ifndef RM_SKIP_WAVES
 #define RM_SKIP_WAVES 5
 #endif
-template <bool ROT, int SCL>
+template <bool ROT, int SCL, bool BIG>
 __global__ __launch_bounds__(256, RM_SKIP_WAVES) void rm_coop_kernelN_skip(const RmParams U) {
     __shared__ float s_xw[2 * 4 * 64];
     __shared__ float s_x4[4 * 4 * 64];
@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256, RM_SKIP_WAVES) void rm_coop_kernelN_skip(const
     const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const SceneNCoop<ROT, SCL> coop = rm_make_coop_scene<ROT, SCL>(U, t, (RM_LDS float *)s_xw, (RM_LDS float *)s_x4, false);
     const int chunk = (1 << (32 - __builtin_clz((unsigned)U.n_prims - 1u))) >> 2;
-    rmx::SceneNSkip<ROT, SCL> sc(coop, chunk);
+    rmx::SceneNSkip<ROT, SCL, BIG> sc(coop, chunk);
 #ifdef RM_SKIP_STATS
     __shared__ unsigned s_stat[8];
     sc.st_lds = (RM_LDS unsigned *)s_stat;
@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256, RM_SKIP_WAVES) void rm_coop_kernelN_skip(const
 template <bool ROT, int SCL>
 hipError_t launch_skip_variant(const RmParams &U, dim3 grid, hipStream_t stream) {
     const size_t lds = (size_t)U.n_prims * sizeof(RmPrimDev);
-    hipLaunchKernelGGL((rm_coop_kernelN_skip<ROT, SCL>), grid, dim3(256), lds, stream, U);
+    if (U.n_prims > 256) hipLaunchKernelGGL((rm_coop_kernelN_skip<ROT, SCL, true>), grid, dim3(256), lds, stream, U);
+    else                 hipLaunchKernelGGL((rm_coop_kernelN_skip<ROT, SCL, false>), grid, dim3(256), lds, stream, U);
     return hipGetLastError();
 }
 

@@ -55,7 +55,9 @@ RM_DI RmPrimDev lane_record(RmLdsPrimPtr T, int i) {
     return u.p;
 }
 
-template <bool ROT, int SCL>
+// BIG: quarters of 128 leaves (tables of 257 to 512 primitives); kept apart so that the smaller tables do not carry the
+// second half's code (the 256-primitive stress scene was 2.7 % slower with both in one kernel)
+template <bool ROT, int SCL, bool BIG>
 struct SceneNSkip {
     typedef SceneN<ROT, SCL, true> Part;
     const SceneNCoop<ROT, SCL> &coop;
@@ -70,7 +72,7 @@ struct SceneNSkip {
 #endif
 
     RM_DI SceneNSkip(const SceneNCoop<ROT, SCL> &c, int chunk) : coop(c) {
-        cullable = c.part.n == chunk && chunk >= RM_SKIP_MIN_CHUNK && chunk <= RM_SKIP_MAX_CHUNK;
+        cullable = c.part.n == chunk && chunk >= RM_SKIP_MIN_CHUNK && chunk <= (BIG ? RM_SKIP_MAX_CHUNK : 64) && (!BIG || chunk > 64);
         groups = chunk >> 2;
         all[0] = chunk >= 64 ? ~0ull : ((1ull << chunk) - 1ull);
         all[1] = chunk > 64 ? ~0ull : 0ull;
@@ -92,13 +94,14 @@ struct SceneNSkip {
         const float hd = 0.5f * __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez) * 1.0001f + 1e-5f * (fabsf(cx) + fabsf(cy) + fabsf(cz)) + 0.01f +
                          1.7321f * grow;
         const int j = (int)coop.lane;
-        const int n_leaves = 4 * groups, halves = n_leaves > 64 ? 2 : 1;
+        const int n_leaves = 4 * groups;
+        constexpr int halves = BIG ? 2 : 1;
         bool bad = !(fabsf(cx) + fabsf(cy) + fabsf(cz) + hd <= RM_SKIP_RANGE);          // also true for NaN
         unsigned long long keep[2] = {0ull, 0ull};
         float lb_half0 = inf;           // lower bound of leaves 0..63 as a block (chunks of 128)
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {
-            if (hf >= halves) break;
+            if (hf >= halves) break;           // (compile time)
             const bool mine = 64 * hf + j < n_leaves;
             float lb = inf, ub = inf;
             if (mine) {
@@ -160,13 +163,14 @@ struct SceneNSkip {
     }
     // this wave's chunk: the binary-counter walk of SceneN::tree over the groups that are present
     RM_DI float walk(V3 p) const {
-        float st[RM_SKIP_LEVELS];
+        constexpr int LEVELS = BIG ? RM_SKIP_LEVELS : RM_SKIP_LEVELS - 1;
+        float st[LEVELS];
 #pragma unroll
-        for (int l = 0; l < RM_SKIP_LEVELS; l++) st[l] = 0.0f;
+        for (int l = 0; l < LEVELS; l++) st[l] = 0.0f;
         unsigned pres = 0;                                      // bit l: st[l] holds a subtree (else it was skipped)
         float v = 0.0f;
         for (int g = 0; g < groups; g++) {
-            const unsigned m4 = (unsigned)((g < 16 ? mask[0] : mask[1]) >> (4 * (g & 15))) & 15u;
+            const unsigned m4 = BIG ? (unsigned)((g < 16 ? mask[0] : mask[1]) >> (4 * (g & 15))) & 15u : (unsigned)(mask[0] >> (4 * g)) & 15u;
             const int merges = __builtin_ctz(~(unsigned)g);     // trailing ones of g = finished lower levels
             const unsigned below = (1u << merges) - 1u;
             if (m4 == 0u) {                                     // a skipped block is a whole left operand: nothing below it is kept
@@ -175,10 +179,10 @@ struct SceneNSkip {
             }
             v = group(g, m4, p);
 #pragma unroll
-            for (int l = 0; l < RM_SKIP_LEVELS - 1; l++)
+            for (int l = 0; l < LEVELS - 1; l++)
                 if (l < merges && ((pres >> l) & 1u)) v = rm_smin_w(st[l], v);
 #pragma unroll
-            for (int l = 0; l < RM_SKIP_LEVELS; l++) if (l == merges) st[l] = v;
+            for (int l = 0; l < LEVELS; l++) if (l == merges) st[l] = v;
             pres = (pres & ~below) | (1u << merges);
         }
         return v;
