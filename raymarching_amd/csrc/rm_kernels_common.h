@@ -658,9 +658,15 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
                 const bool spread = cost >= RM_HEAVY_DILATE * Q.heavy_threshold;
                 bool add = false;
                 unsigned nt = tile;
+                // the tile's column and row again, by the same multiplications as before the render (kept in registers
+                // across the march they would cost more than this rare recomputation)
+                unsigned base = 0, t2 = tile;
+                if (SHAPE == 2 || (!PLAIN && U.n_poses != 1)) {
+                    const unsigned per_pose = Q.tiles_x * Q.tiles_y;
+                    base = (tile / per_pose) * per_pose; t2 = tile - base;
+                }
+                const int ty = (int)(unsigned)(((unsigned long long)t2 * Q.tx_magic) >> 37), tx = (int)(t2 - (unsigned)ty * Q.tiles_x);
                 if (lane < 9 && (spread || lane == 4)) {
-                    const unsigned per_pose = Q.tiles_x * Q.tiles_y, base = tile - tile % per_pose, t2 = tile - base;
-                    const int ty = (int)(t2 / Q.tiles_x), tx = (int)(t2 - (unsigned)ty * Q.tiles_x);
                     const int nx = tx + lane % 3 - 1, ny = ty + lane / 3 - 1;
                     if (nx >= 0 && ny >= 0 && nx < (int)Q.tiles_x && ny < (int)Q.tiles_y) {
                         nt = base + (unsigned)ny * Q.tiles_x + (unsigned)nx;
