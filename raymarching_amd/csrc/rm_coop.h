@@ -12,6 +12,9 @@
 // first leaf of its right operand, which for the three top nodes are leaves C, 3C and 2C.
 #include "rm_kernels_common.h"
 
+// leaves per wave when the four waves of a workgroup split a table of n >= 3 primitives: pow2ceil(n) / 4
+__host__ __device__ inline int rm_coop_chunk(int n_prims) { return (1 << (32 - __builtin_clz((unsigned)n_prims - 1u))) >> 2; }
+
 namespace {
 
 template <bool ROT, int SCL>
@@ -77,8 +80,7 @@ RM_DI SceneNCoop<ROT, SCL> rm_make_coop_scene(const RmParams &U, PrimTable<true>
     // the wave index is the same in every lane: as a scalar, the chunk bounds and with them the whole table walk stay on
     // the scalar unit (left as a vector value, the walk becomes a divergent loop with exec-mask bookkeeping)
     const unsigned lane = threadIdx.x & 63u, wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // chunk = pow2ceil(n) / 4 >= 1 for n >= 3
-    const int chunk = (1 << (32 - __builtin_clz((unsigned)U.n_prims - 1u))) >> 2;
+    const int chunk = rm_coop_chunk(U.n_prims);               // >= 1 for n >= 3
     const int lo = (int)wv * chunk;
     int cnt = U.n_prims - lo;
     cnt = cnt < 0 ? 0 : (cnt > chunk ? chunk : cnt);

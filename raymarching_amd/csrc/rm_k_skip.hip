@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256, RM_SKIP_WAVES) void rm_coop_kernelN_skip(const
     t.T = rm_stage_table(U, 0);                                           // ends with a __syncthreads()
     const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const SceneNCoop<ROT, SCL> coop = rm_make_coop_scene<ROT, SCL>(U, t, (RM_LDS float *)s_xw, (RM_LDS float *)s_x4, false);
-    const int chunk = (1 << (32 - __builtin_clz((unsigned)U.n_prims - 1u))) >> 2;
+    const int chunk = rm_coop_chunk(U.n_prims);
     rmx::SceneNSkip<ROT, SCL, BIG> sc(coop, chunk);
 #ifdef RM_SKIP_STATS
     __shared__ unsigned s_stat[8];
@@ -53,7 +53,7 @@ hipError_t launch_skip_variant(const RmParams &U, dim3 grid, hipStream_t stream)
 
 bool rm_skip_applies(const RmParams &U) {
     if (U.body != RM_BODY_PRIMS || U.lds_prims != U.n_prims || U.n_prims < 3 || (U.scene_flags & RM_SF_CSG)) return false;
-    const int chunk = (1 << (32 - __builtin_clz((unsigned)U.n_prims - 1u))) >> 2;
+    const int chunk = rm_coop_chunk(U.n_prims);
     return chunk >= RM_SKIP_MIN_CHUNK && chunk <= RM_SKIP_MAX_CHUNK;
 }
 

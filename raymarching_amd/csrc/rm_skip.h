@@ -59,7 +59,6 @@ RM_DI RmPrimDev lane_record(RmLdsPrimPtr T, int i) {
 // second half's code (the 256-primitive stress scene was 2.7 % slower with both in one kernel)
 template <bool ROT, int SCL, bool BIG>
 struct SceneNSkip {
-    typedef SceneN<ROT, SCL, true> Part;
     const SceneNCoop<ROT, SCL> &coop;
     bool cullable;                 // this wave's chunk is complete and has RM_SKIP_MIN_CHUNK..RM_SKIP_MAX_CHUNK leaves
     int groups;                    // leaves of the chunk / 4, a power of two
