@@ -556,11 +556,13 @@ def random_case(seed: int) -> Case:
     return Case(f"random_{seed}", w, h, setup=setup, prims=prims, src=use_src, sdepth=use_sd)
 
 
-def random_table_case(seed: int) -> Case:
+def random_table_case(seed: int, world_scale: float = 1.0) -> Case:
     """A seeded random plain smooth union of 33..512 primitives of all five kinds (the tables whose marches cull exactly):
     dense or sparse placement, any rotation, scales in [.3, 2.3] (some unit, some identity rotations, sometimes the whole
     table without rotation or scale), random camera looking at the origin from inside or outside the cloud, random march
-    uniforms, sometimes a source image / depth texture."""
+    uniforms, sometimes a source image / depth texture.  world_scale multiplies every length of the scene but the blend
+    radius of smin: small worlds blend everything (nothing can be skipped), large ones put coordinates near and beyond the
+    range the culling's rounding margin is sized for."""
     rng = scenes.SplitMix64(0x7AB1E000 + seed)
     u = rng.uniform
     w, h = 24 + int(u() * 56), 16 + int(u() * 32)
@@ -579,14 +581,15 @@ def random_table_case(seed: int) -> Case:
         params = [(0.5 + u(),), (0.5 + u(), 0.5 + u(), 0.5 + u()), (0.3 + u(), 0.2 + 0.5 * u(), 0.05 + 0.1 * u()),
                   (0.3 + 0.5 * u(), 0.3 + 0.5 * u()), (0.4 + 0.4 * u(), 0.1 + 0.2 * u())][t]
         ident, unit = no_rot or u() < 0.2, no_scale or u() < 0.2
-        prims.append({"type": t, "op": 0, "pos": [float(F((u() * 2 - 1) * e)) for e in ext],
+        params = tuple(float(F(v * world_scale)) for v in params)
+        prims.append({"type": t, "op": 0, "pos": [float(F((u() * 2 - 1) * e * world_scale)) for e in ext],
                       "quat": [0.0, 0.0, 0.0, 1.0] if ident else [float(F(x)) for x in quat()],
                       "scale": [1.0, 1.0, 1.0] if unit else [float(F(0.3 + 2.0 * u())) for _ in range(3)],
                       "color": [float(F(0.25 + 0.75 * u())) for _ in range(3)], "params": params})
-    floats = {"_MaxSteps": float(int(20 + u() * 150)), "_MaxDist": float(F(15 + u() * 60)), "_StepFactor": float(F(0.3 + u() * 0.7)),
-              "_NormalSampleScale": float(F(10 ** (-5 + 3 * u())))}
+    floats = {"_MaxSteps": float(int(20 + u() * 150)), "_MaxDist": float(F((15 + u() * 60) * max(1.0, world_scale))),
+              "_StepFactor": float(F(0.3 + u() * 0.7)), "_NormalSampleScale": float(F(10 ** (-5 + 3 * u())))}
     az, el = u() * 2 * math.pi, (u() - 0.5) * 1.4
-    dist = (0.2 + u() * 1.8) * max(ext)
+    dist = (0.2 + u() * 1.8) * max(ext) * world_scale
     pos = np.array([dist * math.cos(el) * math.sin(az), dist * math.sin(el), -dist * math.cos(el) * math.cos(az)])
     fov = 40 + u() * 60
     light = [u() * 2 - 1, u(), u() * 2 - 1, 0.0]
@@ -601,4 +604,4 @@ def random_table_case(seed: int) -> Case:
         for k, v in floats.items():
             mat.SetFloat(k, v)
 
-    return Case(f"random_table_{seed}", w, h, setup=setup, prims=prims, src=use_src, sdepth=use_sd)
+    return Case(f"random_table_{seed}_x{world_scale:g}", w, h, setup=setup, prims=prims, src=use_src, sdepth=use_sd)

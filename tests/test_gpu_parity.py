@@ -448,11 +448,16 @@ def test_random_scenes(oracle, torch_cuda, seed, kernel):
     assert got["stats"]["sum_steps_s"] == ref["stats"]["sum_steps_s"]
 
 
+@pytest.mark.parametrize("world_scale", [1.0, 0.05, 12.0, 60.0])
 @pytest.mark.parametrize("seed", range(40))
-def test_random_plain_tables_with_exact_culling(oracle, torch_cuda, seed):
+def test_random_plain_tables_with_exact_culling(oracle, torch_cuda, seed, world_scale):
     """seeded random smooth unions of 33..512 primitives, the tables whose marches skip subtrees: bit-exact against the
-    oracle (automatic kernel choice)"""
-    case = cases.random_table_case(seed)
+    oracle (automatic kernel choice).  The world scales put the scene's lengths at a twentieth (everything blends), at
+    twelve times (coordinates in the hundreds: the largest rounding errors the margin has to cover) and at sixty times the
+    blend radius's scale (coordinates beyond the range in which anything is skipped)"""
+    if world_scale != 1.0 and seed >= 16:
+        pytest.skip("16 seeds per extra scale")
+    case = cases.random_table_case(seed, world_scale)
     ref = cases.oracle_run(case, oracle)
     got = gpu_run(case, torch_cuda)
     assert_frame_equal(got, ref, case.name)
