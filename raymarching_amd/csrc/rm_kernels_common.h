@@ -28,7 +28,7 @@
 // words per block in the counter-slot buffer; a timeline build (developer tool) appends
 // start/end timestamps of the block (100 MHz s_memrealtime) and its hardware id
 #ifdef RM_TIMELINE
-#define RM_SLOT_WORDS 8
+#define RM_SLOT_WORDS 16      // + the wave's last four tiles: start time (10 ns units after the wave's start) and cost << 20 | queue entry
 #else
 #define RM_SLOT_WORDS 3
 #endif
@@ -498,6 +498,7 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
 #ifdef RM_TIMELINE
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
     unsigned n_done = 0, max_cost = 0, t_wait = 0, n_claims = 0;
+    unsigned tl_t[4] = {0, 0, 0, 0}, tl_c[4] = {0, 0, 0, 0}, tl_t0 = 0;
 #endif
 
     unsigned n_heavy = 0;
@@ -606,6 +607,9 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
         bool have = false;
         unsigned tile = cur == 0xffffffffu ? 0xffffffffu : entry_tile(cur);
         unsigned t_hit = 0, t_p = 0, t_s = 0;
+#ifdef RM_TIMELINE
+        tl_t0 = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_start);
+#endif
         if (tile != 0xffffffffu) {
             // a tile from the heavy list is a long dependent chain that the frame cannot end before:
             // its wave gets issue priority over waves rendering cheap tiles on the same SIMD
@@ -649,6 +653,8 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
             const unsigned cost = rm_wave_max(t_p + t_s + (t_hit ? 7u : 0u));
 #ifdef RM_TIMELINE
             n_done++; max_cost = max_cost > cost ? max_cost : cost;
+            tl_t[0] = tl_t[1]; tl_t[1] = tl_t[2]; tl_t[2] = tl_t[3]; tl_t[3] = tl_t0;
+            tl_c[0] = tl_c[1]; tl_c[1] = tl_c[2]; tl_c[2] = tl_c[3]; tl_c[3] = (cost << 20) | (cur & 0xfffffu);
 #endif
 #if RM_HEAVY_DILATE
             // A camera that moves carries a long tile into a neighbouring one by the next frame: a tile well above the
@@ -705,6 +711,7 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
         o[3] = (unsigned)t_start; o[4] = (unsigned)(t_start >> 32); o[5] = (unsigned)t_end; o[6] = (unsigned)(t_end >> 32);
         o[7] = n_done | (max_cost << 16);
         o[0] = t_wait; o[1] = n_claims;       // timeline builds repurpose the counters
+        for (int k = 0; k < 4; k++) { o[8 + 2 * k] = tl_t[k]; o[9 + 2 * k] = tl_c[k]; }
 #endif
     }
 }

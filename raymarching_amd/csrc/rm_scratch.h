@@ -4,12 +4,14 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include "rm_device.h"
 
 #define RM_SCRATCH_MAX_DEVICES 64
 // one heavy-tile bitmap: 160 K tiles of 8x8 pixels (a 3840x2160 frame has 129 600)
 #define RM_SCRATCH_BM_WORDS    5120u
-// queue state: claim counters and heavy counts (1088 words), three heavy lists of 8192 entries, three bitmaps
-#define RM_SCRATCH_QUEUE_BYTES ((size_t)(1088u + 3u * 8192u + 3u * RM_SCRATCH_BM_WORDS) * 4u)
+// queue state: claim counters and heavy counts (1088 words with 8 counters per set), three heavy lists of 8192 entries,
+// three bitmaps
+#define RM_SCRATCH_QUEUE_BYTES ((size_t)(2u * RM_Q_SHARDS * RM_Q_STRIDE + 64u + 3u * 8192u + 3u * RM_SCRATCH_BM_WORDS) * 4u)
 // counter slots: 32768 slots of three words = one slot per 16x16-pixel block of a 3840x2160 frame (32 400)
 #define RM_SCRATCH_SLOT_BYTES  ((size_t)32768u * 12u)
 #define RM_SCRATCH_STATS_BYTES ((size_t)256u)

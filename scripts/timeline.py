@@ -17,7 +17,7 @@ mat._ck(mat._lib.rm_debug_counter_slots(mat.handle, None, 0, C.byref(wps), C.byr
 buf = np.zeros(wps.value * ns.value, dtype=np.uint32)
 mat._ck(mat._lib.rm_debug_counter_slots(mat.handle, buf.ctypes.data_as(C.POINTER(C.c_uint32)), buf.size, None, None))
 s = buf.reshape(ns.value, wps.value)
-assert wps.value == 8, "not a timeline build"
+assert wps.value == 16, "not a timeline build"
 t0 = s[:, 3].astype(np.uint64) | (s[:, 4].astype(np.uint64) << np.uint64(32))
 t1 = s[:, 5].astype(np.uint64) | (s[:, 6].astype(np.uint64) << np.uint64(32))
 base = t0.min()
@@ -38,8 +38,14 @@ resident = [(int(((st <= t) & (en > t)).sum())) for t in edges]
 print("resident blocks every 5 us:", resident)
 started = [int((st <= t).sum()) for t in edges]
 print("started blocks every 5 us:", started)
-late = np.argsort(en)[::-1][:12]
-print("the waves that end last: (end us, tiles done, longest tile in evaluations, started on a heavy tile)")
-nh = int(os.environ.get("RM_NHEAVY", "0"))
+late = np.argsort(en)[::-1][:16]
+print("the waves that end last: end us, tiles done, longest tile; then their last four tiles as start us (in the frame) / cost in evaluations / queue entry")
 for b in late:
-    print("   %6.1f  %3d  %4d" % (en[b], s[b, 7] & 0xffff, s[b, 7] >> 16))
+    tiles = ["%6.1f/%3d/%6d" % (st[b] + s[b, 8 + 2 * k] / 100.0, s[b, 9 + 2 * k] >> 20, s[b, 9 + 2 * k] & 0xfffff) for k in range(4)]
+    print("   %6.1f  %3d  %4d   %s" % (en[b], s[b, 7] & 0xffff, s[b, 7] >> 16, "  ".join(tiles)))
+# how much work started in the last stretch of the frame
+last_start = st + s[:, 14] / 100.0
+print("waves whose last tile started in the last 30 / 20 / 10 us of the frame:", [int((last_start > en.max() - d).sum()) for d in (30, 20, 10)])
+cost_last = s[:, 15] >> 20
+late_mask = last_start > en.max() - 30
+print("cost of those last tiles (evaluations): mean %.1f max %d; of all last tiles: mean %.1f" % (cost_last[late_mask].mean(), cost_last[late_mask].max(), cost_last.mean()))
