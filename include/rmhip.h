@@ -256,8 +256,8 @@ int rm_get_stats(rm_ctx *ctx, rm_stats *out);
 int rm_debug_counter_slots(rm_ctx *ctx, uint32_t *out, int max_words, int *words_per_slot, int *n_slots);
 /* Kernel variant for the next blits, no counterpart in the reference.  0 = automatic (the default).  1..3 and 5 are exact
  * kernels whose frames are bit-identical: 1 one wave per 8x8 tile, 2 persistent tile queue, 3 persistent waves with lane
- * refill, 5 four waves per tile that split the primitive table (tables of 3 to 512 primitives; others take 1; plain smooth
- * unions of 33 to 512 primitives also skip the subtrees that cannot change a bit of a march step's result, unless the
+ * refill, 5 four waves per tile that split the primitive table (tables of 3 to 512 primitives; others take 1; tables of 33 to 512
+ * primitives, from 65 with op bits, also skip the subtrees that cannot change a bit of a march step's result, unless the
  * float property _RmTableSkip is 0).  4 = the
  * opt-in tolerance kernels (fused multiply-adds and hardware sqrt/rcp in the march loops; per-step culling for
  * smooth-union tables): frames within the port's tolerance, not bit-identical. */

@@ -819,7 +819,7 @@ int launch(rm_ctx *c, const RmParams &U, hipStream_t stream, WorkMem M, bool rec
         rc = ensure_partials(c, M, n_blocks);
         if (rc) return rc;
         P.partials = *M.partials;
-        // plain smooth unions of 33 to 512 primitives: the shared tile with exact culling in the marches (same bits;
+        // tables of 33 to 512 primitives (from 65 with op bits): the shared tile with exact culling in the marches (same bits;
         // _RmTableSkip 0 keeps the full table walk)
         const bool skip = coop && plain && rm_skip_applies(P) && getf(c, "_RmTableSkip", 1.0f) != 0.0f;
         if (cull && plain) RM_HIP(c, rm_launch_cull_tiles(P, stream));

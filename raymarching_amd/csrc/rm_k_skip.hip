@@ -1,4 +1,4 @@
-// rm_k_skip.hip -- plain smooth-union tables on the shared-tile kernel with exact culling (rm_skip.h): one launch block per
+// rm_k_skip.hip -- tables on the shared-tile kernel with exact culling (rm_skip.h): one launch block per
 // 8x8 pixel tile, its four waves march the same 64 rays and each walks a quarter of the table, skipping the left subtrees
 // that provably cannot change a bit of the result.  Frames are bit-identical to the other exact kernels'.  Compiled
 // without the SLP vectoriser like the other table kernels.
@@ -11,16 +11,17 @@ namespace {
 #ifndef RM_SKIP_WAVES
 #define RM_SKIP_WAVES 5
 #endif
-template <bool ROT, int SCL, bool BIG>
-__global__ __launch_bounds__(256, RM_SKIP_WAVES) void rm_coop_kernelN_skip(const RmParams U) {
+// (with op bits a fifth resident block would cost over 100 bytes of scratch, as in rm_k_coop.hip: those stay at four waves)
+template <bool ROT, int SCL, bool BIG, bool CSG>
+__global__ __launch_bounds__(256, CSG ? 4 : RM_SKIP_WAVES) void rm_coop_kernelN_skip(const RmParams U) {
     __shared__ float s_xw[2 * 4 * 64];
     __shared__ float s_x4[4 * 4 * 64];
     PrimTable<true> t;
     t.T = rm_stage_table(U, 0);                                           // ends with a __syncthreads()
     const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const SceneNCoop<ROT, SCL> coop = rm_make_coop_scene<ROT, SCL>(U, t, (RM_LDS float *)s_xw, (RM_LDS float *)s_x4, false);
+    const SceneNCoop<ROT, SCL> coop = rm_make_coop_scene<ROT, SCL>(U, t, (RM_LDS float *)s_xw, (RM_LDS float *)s_x4, CSG);
     const int chunk = rm_coop_chunk(U.n_prims);
-    rmx::SceneNSkip<ROT, SCL, BIG> sc(coop, chunk);
+    rmx::SceneNSkip<ROT, SCL, BIG, CSG> sc(coop, chunk);
 #ifdef RM_SKIP_STATS
     __shared__ unsigned s_stat[8];
     sc.st_lds = (RM_LDS unsigned *)s_stat;
@@ -44,20 +45,25 @@ __global__ __launch_bounds__(256, RM_SKIP_WAVES) void rm_coop_kernelN_skip(const
 template <bool ROT, int SCL>
 hipError_t launch_skip_variant(const RmParams &U, dim3 grid, hipStream_t stream) {
     const size_t lds = (size_t)U.n_prims * sizeof(RmPrimDev);
-    if (U.n_prims > 256) hipLaunchKernelGGL((rm_coop_kernelN_skip<ROT, SCL, true>), grid, dim3(256), lds, stream, U);
-    else                 hipLaunchKernelGGL((rm_coop_kernelN_skip<ROT, SCL, false>), grid, dim3(256), lds, stream, U);
+    const bool big = U.n_prims > 256, csg = (U.scene_flags & RM_SF_CSG) != 0;
+    if (big && csg)  hipLaunchKernelGGL((rm_coop_kernelN_skip<ROT, SCL, true, true>), grid, dim3(256), lds, stream, U);
+    else if (big)    hipLaunchKernelGGL((rm_coop_kernelN_skip<ROT, SCL, true, false>), grid, dim3(256), lds, stream, U);
+    else if (csg)    hipLaunchKernelGGL((rm_coop_kernelN_skip<ROT, SCL, false, true>), grid, dim3(256), lds, stream, U);
+    else             hipLaunchKernelGGL((rm_coop_kernelN_skip<ROT, SCL, false, false>), grid, dim3(256), lds, stream, U);
     return hipGetLastError();
 }
 
 }  // namespace
 
 bool rm_skip_applies(const RmParams &U) {
-    if (U.body != RM_BODY_PRIMS || U.lds_prims != U.n_prims || U.n_prims < 3 || (U.scene_flags & RM_SF_CSG)) return false;
+    if (U.body != RM_BODY_PRIMS || U.lds_prims != U.n_prims || U.n_prims < 3) return false;
     const int chunk = rm_coop_chunk(U.n_prims);
-    return chunk >= RM_SKIP_MIN_CHUNK && chunk <= RM_SKIP_MAX_CHUNK;
+    // (tables with op bits run at four waves per SIMD, where quarters of 16 leaves lose: 37 primitives 1.78 -> 1.96 ms)
+    const int min_chunk = (U.scene_flags & RM_SF_CSG) ? 2 * RM_SKIP_MIN_CHUNK : RM_SKIP_MIN_CHUNK;
+    return chunk >= min_chunk && chunk <= RM_SKIP_MAX_CHUNK;
 }
 
-// plain smooth-union tables staged whole in LDS whose quarter is 16 to 128 primitives (33 to 512 primitives); same grid and
+// tables staged whole in LDS whose quarter is 16 to 128 primitives (33 to 512 primitives; from 65 with op bits); same grid and
 // counter slots as rm_launch_coop_tiles
 hipError_t rm_launch_coop_skip_tiles(const RmParams &U, hipStream_t stream) {
     if (U.w <= 0 || U.rows <= 0 || U.n_poses <= 0 || !rm_skip_applies(U)) return hipErrorInvalidValue;

@@ -66,7 +66,7 @@ hipError_t rm_launch_cull_tiles(const RmParams &U, hipStream_t stream);
 #endif
 unsigned rm_coop_blocks(int w, int rows, int n_poses);
 hipError_t rm_launch_coop_tiles(const RmParams &U, hipStream_t stream);
-// the same kernel with exact culling in the two marches (rm_skip.h): plain smooth unions (no op bits) of 33 to 512
-// primitives; rm_skip_applies() says whether U is one
+// the same kernel with exact culling in the two marches and the normal taps (rm_skip.h): tables of 33 to 512 primitives, 65
+// to 512 with op bits; rm_skip_applies() says whether U is one
 bool rm_skip_applies(const RmParams &U);
 hipError_t rm_launch_coop_skip_tiles(const RmParams &U, hipStream_t stream);

@@ -1,5 +1,5 @@
 #pragma once
-// rm_skip.h -- exact culling for plain smooth-union tables in the shared-tile kernel: a march step evaluates only the
+// rm_skip.h -- exact culling for table scenes in the shared-tile kernel: a march step evaluates only the
 // primitives that can reach the result, and the result keeps every bit.
 //
 // smin(a, b, .5) (Assets/Raymarching.cginc:110-113) is h = clamp(.5 + (b - a), 0, 1); lerp(b, a, h) - .5*h*(1-h), evaluated
@@ -57,7 +57,11 @@ RM_DI RmPrimDev lane_record(RmLdsPrimPtr T, int i) {
 
 // BIG: quarters of 128 leaves (tables of 257 to 512 primitives); kept apart so that the smaller tables do not carry the
 // second half's code (the 256-primitive stress scene was 2.7 % slower with both in one kernel)
-template <bool ROT, int SCL, bool BIG>
+// CSG: the table carries op bits.  An smax node (cginc:120-123 as SceneN::comb evaluates it: h = clamp(.5 + (a - b)))
+// returns its right operand bit for bit once the LEFT one is .5 BELOW it, and lies in [max(a, b) - 1/6, max(a, b)]; a
+// negated leaf swaps its bounds.  A skipped left operand leaves b - (+0) = b under an smax node and b - (-0) = b + 0 under
+// an smin node, which differ for b = -0 (a negated leaf can return it).
+template <bool ROT, int SCL, bool BIG, bool CSG>
 struct SceneNSkip {
     const SceneNCoop<ROT, SCL> &coop;
     bool cullable;                 // this wave's chunk is complete and has RM_SKIP_MIN_CHUNK..RM_SKIP_MAX_CHUNK leaves
@@ -71,7 +75,7 @@ struct SceneNSkip {
 #endif
 
     RM_DI SceneNSkip(const SceneNCoop<ROT, SCL> &c, int chunk) : coop(c) {
-        cullable = c.part.n == chunk && chunk >= RM_SKIP_MIN_CHUNK && chunk <= (BIG ? RM_SKIP_MAX_CHUNK : 64) && (!BIG || chunk > 64);
+        cullable = c.part.n == chunk && chunk >= (CSG ? 2 * RM_SKIP_MIN_CHUNK : RM_SKIP_MIN_CHUNK) && chunk <= (BIG ? RM_SKIP_MAX_CHUNK : 64) && (!BIG || chunk > 64);
         groups = chunk >> 2;
         all[0] = chunk >= 64 ? ~0ull : ((1ull << chunk) - 1ull);
         all[1] = chunk > 64 ? ~0ull : 0ull;
@@ -97,15 +101,16 @@ struct SceneNSkip {
         constexpr int halves = BIG ? 2 : 1;
         bool bad = !(fabsf(cx) + fabsf(cy) + fabsf(cz) + hd <= RM_SKIP_RANGE);          // also true for NaN
         unsigned long long keep[2] = {0ull, 0ull};
-        float lb_half0 = inf;           // lower bound of leaves 0..63 as a block (chunks of 128)
+        float lb_half0 = inf, ub_half0 = inf;           // bounds of leaves 0..63 as a block (chunks of 128)
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {
             if (hf >= halves) break;           // (compile time)
             const bool mine = 64 * hf + j < n_leaves;
-            float lb = inf, ub = inf;
+            float lb = inf, ub = inf, osg = 1.0f;
             if (mine) {
                 const RmPrimDev P = lane_record(coop.part.tab.T, 64 * hf + j);
-                const float d = rm_prim_typed<ROT, SCL>(P, P.type & RM_TYPE_MASK, mk3(cx, cy, cz), coop.part.tiny);
+                float d = rm_prim_typed<ROT, SCL>(P, P.type & RM_TYPE_MASK, mk3(cx, cy, cz), coop.part.tiny);
+                if (CSG) { d = d * P.nsgn; osg = P.osgn; }
                 // (a negative scale would make min(scale) the largest in magnitude and the leaf steeper than 1)
                 bad = bad || !(fabsf(d) + hd <= RM_SKIP_RANGE) || !(fabsf(P.px) + fabsf(P.py) + fabsf(P.pz) <= RM_SKIP_RANGE) ||
                       (SCL != RM_SCL_UNIT && !(P.ms > 0.0f));
@@ -118,18 +123,34 @@ struct SceneNSkip {
 #pragma unroll
             for (int l = 0; l < 6; l++) {
                 const float sub = __shfl_xor(ub, 1 << l), slb = __shfl_xor(lb, 1 << l);
-                skip = skip || (!((j >> l) & 1) && sub + (0.5f + 0.126f * (float)l) <= lb);
-                ub = fminf(ub, sub);
-                lb = fminf(lb, slb);
+                const bool left = !((j >> l) & 1);
+                if (!CSG) {
+                    skip = skip || (left && sub + (0.5f + 0.126f * (float)l) <= lb);
+                    ub = fminf(ub, sub);
+                    lb = fminf(lb, slb);
+                } else {
+                    // the node's op sits in the first leaf of its right operand; here the bounds carry their slack along
+                    const bool smax = __shfl(osg, ((j >> l) | 1) << l) < 0.0f;
+                    const float lbL = left ? lb : slb, ubL = left ? ub : sub, lbR = left ? slb : lb, ubR = left ? sub : ub;
+                    skip = skip || (left && (smax ? ubL + 0.5f <= lbR : ubR + 0.5f <= lbL));
+                    ub = smax ? fmaxf(ub, sub) : fminf(ub, sub);
+                    lb = smax ? fmaxf(lb, slb) - 0.168f : fminf(lb, slb) - 0.126f;
+                }
             }
             // (after the butterfly lb and ub are those of all 64 leaves of this half, in every lane)
             const unsigned long long k = __ballot(mine && !skip);
             if (hf == 0) {
-                lb_half0 = lb;
+                lb_half0 = lb; ub_half0 = ub;
                 keep[0] = k;
             } else {
                 keep[1] = k;
-                if (__all(ub + (0.5f + 0.126f * 6.0f) <= lb_half0)) keep[0] = 0ull;      // the first half as a block against the second
+                // the first half as a block against the second
+                if (!CSG) {
+                    if (__all(ub + (0.5f + 0.126f * 6.0f) <= lb_half0)) keep[0] = 0ull;
+                } else {
+                    const bool smax = __shfl(osg, 0) < 0.0f;
+                    if (__all(smax ? ub_half0 + 0.5f <= lb : ub + 0.5f <= lb_half0)) keep[0] = 0ull;
+                }
             }
         }
         if (__any(bad)) return;
@@ -138,27 +159,40 @@ struct SceneNSkip {
 #endif
     }
 
-    RM_DI float leaf(int i, V3 p) const {
-        float s;
-        int tw;
-        return coop.part.template leaf_w<false>(i, p, s, tw);
-    }
-    // group g of four leaves with the leaves m4 names (bit 3, the last leaf, is set whenever any is): an absent left
-    // operand leaves smin(left, right) = right.  Measured and dropped: fetching all four records up front whatever m4 says
-    // (no gain), one rolled loop over the present leaves (18 % slower: the four leaves of a full group overlap in the
-    // pipeline), straight-line code per pattern of present leaves (2 % slower).
-    RM_DI float group(int g, unsigned m4, V3 p) const {
+    RM_DI float leaf(int i, V3 p, float &osgn, int &tw) const { return coop.part.template leaf_w<CSG>(i, p, osgn, tw); }
+    RM_DI static float comb(float a, float b, float s) { return SceneN<ROT, SCL, true>::template comb<CSG>(a, b, s); }
+    // the value of a node whose left operand was skipped, s its op
+    RM_DI static float alone(float b, float s) { return CSG ? b + (s > 0.0f ? 0.0f : -0.0f) : b; }
+    // group g of four leaves a, b, c, d with the leaves m4 names (bit 3, the last leaf, is set whenever any is), as
+    // comb(comb(a, b), comb(c, d)); tw receives the type word of the group's first record, which carries the ops of the
+    // stack merges that follow.  The op of a node sits in the first leaf of its right operand, present or not.
+    // Measured and dropped: fetching all four records up front whatever m4 says (no gain), one rolled loop over the present
+    // leaves (18 % slower: the four leaves of a full group overlap in the pipeline), straight-line code per pattern of
+    // present leaves (2 % slower).
+    RM_DI float group(int g, unsigned m4, V3 p, int &tw) const {
         const int i = g << 2;
+        float sa = 1.0f, sb = 1.0f, sc = 1.0f, sd = 1.0f;
+        int t1 = 0;
+        tw = 0;
         if (m4 == 15u) {
-            const float a = leaf(i, p), b = leaf(i + 1, p), c = leaf(i + 2, p), d = leaf(i + 3, p);
-            return rm_smin_w(rm_smin_w(a, b), rm_smin_w(c, d));
+            const float a = leaf(i, p, sa, tw), b = leaf(i + 1, p, sb, t1), c = leaf(i + 2, p, sc, t1), d = leaf(i + 3, p, sd, t1);
+            return comb(comb(a, b, sb), comb(c, d, sd), sc);
         }
-        const float d = leaf(i + 3, p);
-        const float cd = (m4 & 4u) ? rm_smin_w(leaf(i + 2, p), d) : d;
-        if (!(m4 & 2u)) return cd;
-        const float b = leaf(i + 1, p);
-        const float ab = (m4 & 1u) ? rm_smin_w(leaf(i, p), b) : b;
-        return rm_smin_w(ab, cd);
+        const float d = leaf(i + 3, p, sd, t1);
+        float c = 0.0f;
+        if (m4 & 4u) c = leaf(i + 2, p, sc, t1);
+        else if (CSG) sc = coop.part.tab.get(i + 2).osgn;
+        const float cd = (m4 & 4u) ? comb(c, d, sd) : alone(d, sd);
+        if (!(m4 & 2u)) {
+            if (CSG) tw = coop.part.tab.get(i).type;
+            return alone(cd, sc);
+        }
+        const float b = leaf(i + 1, p, sb, t1);
+        float a = 0.0f;
+        if (m4 & 1u) a = leaf(i, p, sa, tw);
+        else if (CSG) tw = coop.part.tab.get(i).type;
+        const float ab = (m4 & 1u) ? comb(a, b, sb) : alone(b, sb);
+        return comb(ab, cd, sc);
     }
     // this wave's chunk: the binary-counter walk of SceneN::tree over the groups that are present
     RM_DI float walk(V3 p) const {
@@ -176,10 +210,16 @@ struct SceneNSkip {
                 pres &= ~(below | (1u << merges));
                 continue;
             }
-            v = group(g, m4, p);
+            int tw;
+            v = group(g, m4, p, tw);
 #pragma unroll
-            for (int l = 0; l < LEVELS - 1; l++)
-                if (l < merges && ((pres >> l) & 1u)) v = rm_smin_w(st[l], v);
+            for (int l = 0; l < LEVELS - 1; l++) {
+                if (l < merges) {
+                    const float sl = (CSG && ((tw >> (RM_CASCADE_SHIFT + l)) & 1)) ? -1.0f : 1.0f;
+                    if ((pres >> l) & 1u) v = comb(st[l], v, sl);
+                    else if (CSG) v = alone(v, sl);
+                }
+            }
 #pragma unroll
             for (int l = 0; l < LEVELS; l++) if (l == merges) st[l] = v;
             pres = (pres & ~below) | (1u << merges);

@@ -24,7 +24,8 @@ def run(n, skip, frames):
         for k, v in scenes.STRESS_FLOATS.items():
             mat.SetFloat(k, v)
         mat.SetFloat("_RmTableSkip", 1.0 if skip else 0.0)
-        mat.SetPrimitives(scenes.stress_primitives(n, seed=0x5EED0000 + n))
+        mat.SetPrimitives(scenes.csg_random_primitives(n, seed=0x5EED0000 + n) if os.environ.get("RM_CSG") else
+                          scenes.stress_primitives(n, seed=0x5EED0000 + n))
         rt = RenderTexture(w, h, device="cuda:0")
         st = current_stream_handle("cuda:0")
 

@@ -556,14 +556,14 @@ def random_case(seed: int) -> Case:
     return Case(f"random_{seed}", w, h, setup=setup, prims=prims, src=use_src, sdepth=use_sd)
 
 
-def random_table_case(seed: int, world_scale: float = 1.0) -> Case:
+def random_table_case(seed: int, world_scale: float = 1.0, csg: bool = False) -> Case:
     """A seeded random plain smooth union of 33..512 primitives of all five kinds (the tables whose marches cull exactly):
     dense or sparse placement, any rotation, scales in [.3, 2.3] (some unit, some identity rotations, sometimes the whole
     table without rotation or scale), random camera looking at the origin from inside or outside the cloud, random march
     uniforms, sometimes a source image / depth texture.  world_scale multiplies every length of the scene but the blend
     radius of smin: small worlds blend everything (nothing can be skipped), large ones put coordinates near and beyond the
-    range the culling's rounding margin is sized for."""
-    rng = scenes.SplitMix64(0x7AB1E000 + seed)
+    range the culling's rounding margin is sized for.  csg: some nodes are smax, some leaves negated."""
+    rng = scenes.SplitMix64(0x7AB1E000 + seed + (0x1000 if csg else 0))
     u = rng.uniform
     w, h = 24 + int(u() * 56), 16 + int(u() * 32)
 
@@ -582,7 +582,12 @@ def random_table_case(seed: int, world_scale: float = 1.0) -> Case:
                   (0.3 + 0.5 * u(), 0.3 + 0.5 * u()), (0.4 + 0.4 * u(), 0.1 + 0.2 * u())][t]
         ident, unit = no_rot or u() < 0.2, no_scale or u() < 0.2
         params = tuple(float(F(v * world_scale)) for v in params)
-        prims.append({"type": t, "op": 0, "pos": [float(F((u() * 2 - 1) * e * world_scale)) for e in ext],
+        op = 0
+        if csg and i > 0 and u() < 0.15:
+            op |= scenes.OP_SMAX
+        if csg and u() < 0.1:
+            op |= scenes.OP_NEGATE
+        prims.append({"type": t, "op": op, "pos": [float(F((u() * 2 - 1) * e * world_scale)) for e in ext],
                       "quat": [0.0, 0.0, 0.0, 1.0] if ident else [float(F(x)) for x in quat()],
                       "scale": [1.0, 1.0, 1.0] if unit else [float(F(0.3 + 2.0 * u())) for _ in range(3)],
                       "color": [float(F(0.25 + 0.75 * u())) for _ in range(3)], "params": params})
@@ -604,4 +609,4 @@ def random_table_case(seed: int, world_scale: float = 1.0) -> Case:
         for k, v in floats.items():
             mat.SetFloat(k, v)
 
-    return Case(f"random_table_{seed}_x{world_scale:g}", w, h, setup=setup, prims=prims, src=use_src, sdepth=use_sd)
+    return Case(f"random_table_{seed}_x{world_scale:g}{'_csg' if csg else ''}", w, h, setup=setup, prims=prims, src=use_src, sdepth=use_sd)

@@ -150,7 +150,7 @@ def test_cooperative_table_kernel_equals_oracle(oracle, torch_cuda, name, kernel
 
 @pytest.mark.parametrize("name", [c.name for c in cases.SKIP_CASES] + ["stress256_320x180", "stress100_160x90"])
 def test_exact_culling_in_table_marches_equals_oracle(oracle, torch_cuda, name):
-    """plain smooth unions of 33 to 512 primitives: the two marches skip the left subtrees of the smin tree whose value is
+    """tables of 33 to 512 primitives: the two marches skip the left subtrees of the smin tree whose value is
     provably at least k above their right sibling's (smin then returns the right operand bit for bit); the frames and
     counters are the oracle's, and the same with the full table walk (_RmTableSkip 0)"""
     case = cases.BY_NAME[name]
@@ -464,6 +464,22 @@ def test_random_plain_tables_with_exact_culling(oracle, torch_cuda, seed, world_
     assert got["stats"]["n_hit"] == ref["stats"]["n_hit"]
     assert got["stats"]["sum_steps_p"] == ref["stats"]["sum_steps_p"]
     assert got["stats"]["sum_steps_s"] == ref["stats"]["sum_steps_s"]
+
+
+@pytest.mark.parametrize("world_scale", [1.0, 8.0])
+@pytest.mark.parametrize("seed", range(32))
+def test_random_tables_with_op_bits_and_exact_culling(oracle, torch_cuda, seed, world_scale):
+    """the same with smax nodes and negated leaves: an smax node returns its right operand exactly once the left one is
+    .5 below it, so there the bounds change sides"""
+    case = cases.random_table_case(seed, world_scale, csg=True)
+    ref = cases.oracle_run(case, oracle)
+    got = gpu_run(case, torch_cuda)
+    off = gpu_run(case, torch_cuda, floats={"_RmTableSkip": 0.0})
+    for g in (got, off):
+        assert_frame_equal(g, ref, case.name)
+        assert g["stats"]["n_hit"] == ref["stats"]["n_hit"]
+        assert g["stats"]["sum_steps_p"] == ref["stats"]["sum_steps_p"]
+        assert g["stats"]["sum_steps_s"] == ref["stats"]["sum_steps_s"]
 
 
 def test_rgb_pack_round_trip(torch_cuda):
