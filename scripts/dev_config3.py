@@ -50,7 +50,7 @@ with Material() as mat:
     def both():
         shadow()
         frag()
-    for kern, name in ((0, "auto"), (1, "tile")):
+    for kern, name in ((0, "auto"), (1, "tile"), (2, "queue")):
         mat.set_kernel(kern)
         ts = timed(shadow)
         s_stats = mat.stats()
