@@ -127,7 +127,7 @@ def committed_traffic(w: int, h: int):
 # ---- CPU baseline ------------------------------------------------------------------------------------------------
 def cpu_baseline(props: dict, w_main: int, h_main: int) -> dict:
     """The CPU oracle (a port: the reference has no CPU path) on this host's cores: the headline frame itself (best of 2
-    after a warm-up) and, as SURVEY asks, 640x360 and 1920x1080 (best of 5), with every online CPU and with the box's CPU
+    after a warm-up) and the two sizes the reference's own case and the 1080p configuration use, 640x360 and 1920x1080 (best of 5), with every online CPU and with the box's CPU
     share (OMP_NUM_THREADS); the faster thread count is reported.  About 25 core-seconds in all."""
     from oracle import rm_oracle as O
     online = O.lib().rmo_online_cpus()
