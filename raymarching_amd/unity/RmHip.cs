@@ -15,7 +15,7 @@ public static class RmHip
     public const int RM_BODY_PRIMS = 0, RM_BODY_MENGER = 1, RM_BODY_SIERPINSKI = 2, RM_BODY_MANDELBULB = 3, RM_BODY_MANDELBROT = 4, RM_BODY_TERRAIN = 5;
     // rm_set_kernel variants: 0 automatic, 1 tile, 2 persistent queue, 3 lane compaction, 4 tolerance kernel (not bit-exact),
     // 5 four waves per tile that split a primitive table (the automatic choice for tables)
-    public const int RM_KERNEL_AUTO = 0, RM_KERNEL_TILE = 1, RM_KERNEL_QUEUE = 2, RM_KERNEL_STREAM = 3, RM_KERNEL_FAST = 4;
+    public const int RM_KERNEL_AUTO = 0, RM_KERNEL_TILE = 1, RM_KERNEL_QUEUE = 2, RM_KERNEL_STREAM = 3, RM_KERNEL_FAST = 4, RM_KERNEL_COOP = 5;
 
     [StructLayout(LayoutKind.Sequential)]
     public struct Primitive
