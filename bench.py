@@ -673,6 +673,26 @@ def run_multi(args) -> None:
             verified += 1
         del chk
 
+    # ---- the same workload on ONE GPU: rank 0 alone renders all 64 poses (the others wait), after the timed legs -------------
+    # The N = 1 line of this benchmark is the 4K frame, a different workload; a scaling curve must be read from
+    # `one_gpu_same_workload` / `speedup` of each N > 1 line, never from the N = 1 line's value.
+    one_gpu_ms = None
+    if not args.no_one_gpu_reference:
+        if rank == 0:
+            per_call = min(8, N_POSES)
+            f1 = Frame(torch, dev, w, h, per_call)
+            b1 = [pose_arrays(scenes, Raymarching, mat, list(range(b, min(b + per_call, N_POSES))), w, h) for b in range(0, N_POSES, per_call)]
+
+            def step_one(_i):
+                for fcs, c2ws, pos in b1:
+                    blit_poses(mat, fcs, c2ws, pos, f1, w, h, stream)
+
+            k1 = max(1, min(K, 3))
+            el1, _ = timed(torch, step_one, k1, 1)
+            one_gpu_ms = el1 / k1 * 1e3
+            del f1
+        fence()
+
     sec = {}
     if world == 2 and not args.headline_only:
         # ---- configuration 3 on two GPUs: 3840x2160 as interleaved 8-row bands + the directional depth pass on both --------
@@ -685,8 +705,11 @@ def run_multi(args) -> None:
         smd.Update()
         corners = np.ascontiguousarray(np.stack(smd.corners).astype(np.float32).reshape(12))
         fwd = np.ascontiguousarray(t.forward.astype(np.float32))
-        sm_depth = torch.empty((bh, bw), dtype=torch.float32, device=dev)
         rows = m3._lib.rm_band_rows(bh, band, rank, world)
+        sm_depth = torch.empty((rows, bw), dtype=torch.float32, device=dev)          # this rank's bands of the depth map
+        sm_recv = [torch.empty_like(sm_depth) for _ in range(world)] if rank == 0 else None
+        sm_h = torch.empty(sm_depth.shape, dtype=sm_depth.dtype) if gloo_only else None
+        sm_recv_h = [torch.empty_like(sm_h) for _ in range(world)] if (gloo_only and rank == 0) else None
         c = torch.empty((rows, bw, 4), dtype=torch.uint8, device=dev)
         d = torch.empty((rows, bw), dtype=torch.float32, device=dev)
         hm = torch.empty((rows, bw), dtype=torch.uint8, device=dev)
@@ -696,26 +719,48 @@ def run_multi(args) -> None:
         recv_h = [torch.empty_like(rgb_h) for _ in range(world)] if (gloo_only and rank == 0) else None
 
         def step3(_i):
-            m3._ck(m3._lib.rm_shadowmap_directional_device(m3.handle, _fp(corners), _fp(fwd), _ptr(sm_depth), None, bw, bh, stream))
+            m3._ck(m3._lib.rm_shadowmap_directional_bands_device(m3.handle, _fp(corners), _fp(fwd), _ptr(sm_depth), None, bw, bh,
+                                                                 band, rank, world, stream))
             m3._ck(m3._lib.rm_blit_bands_device(m3.handle, None, None, _ptr(c), _ptr(d), _ptr(hm), bw, bh, band, rank, world, stream))
             m3.pack_rgb(c, rgb)
             if gloo_only:
-                rgb_h.copy_(rgb)
+                rgb_h.copy_(rgb); sm_h.copy_(sm_depth)
                 dist.gather(rgb_h, recv_h, dst=0)
+                dist.gather(sm_h, sm_recv_h, dst=0)
                 if rank == 0:
-                    for a, b_ in zip(recv, recv_h):
+                    for a, b_ in zip(recv + sm_recv, recv_h + sm_recv_h):
                         a.copy_(b_)
             else:
                 dist.gather(rgb, recv, dst=0)
+                dist.gather(sm_depth, sm_recv, dst=0)
 
         el3, _ = timed(torch, step3, min(K, 50), min(W, 10), fence)
         el3 = reduce_max(el3)
         s3 = m3.stats()
-        c3 = torch.tensor([float(rays(s3) + bw * bh / world)], dtype=torch.float64, device=cdev)
+        c3 = torch.tensor([float(rays(s3) + rows * bw)], dtype=torch.float64, device=cdev)
         dist.all_reduce(c3, op=dist.ReduceOp.SUM)
-        sec["bands_4k_with_depth_pass_2gpu"] = {"what": "3840x2160 frame as interleaved 8-row bands over 2 GPUs (rm_blit_bands_device) + the full directional "
-                                                        "depth pass on each + RCCL gather of the bands as RGB8, per step",
+        one3 = None
+        if rank == 0 and not args.no_one_gpu_reference:
+            # the same two passes, whole, on rank 0 alone (no gather): the one-GPU point of this configuration
+            fc3, fd3, fh3 = (torch.empty((bh, bw, 4), dtype=torch.uint8, device=dev), torch.empty((bh, bw), dtype=torch.float32, device=dev),
+                             torch.empty((bh, bw), dtype=torch.uint8, device=dev))
+            smf = torch.empty((bh, bw), dtype=torch.float32, device=dev)
+
+            def step3_one(_i):
+                m3._ck(m3._lib.rm_shadowmap_directional_device(m3.handle, _fp(corners), _fp(fwd), _ptr(smf), None, bw, bh, stream))
+                m3._ck(m3._lib.rm_blit_device(m3.handle, None, None, _ptr(fc3), _ptr(fd3), _ptr(fh3), bw, bh, stream))
+
+            e1, _ = timed(torch, step3_one, min(K, 50), min(W, 10))
+            one3 = e1 / min(K, 50) * 1e3
+            del fc3, fd3, fh3, smf
+        fence()
+        sec["bands_4k_with_depth_pass_2gpu"] = {"what": "3840x2160 frame AND the directional depth pass, both as interleaved 8-row bands over 2 GPUs "
+                                                        "(rm_blit_bands_device, rm_shadowmap_directional_bands_device) + gather of the frame bands as RGB8 "
+                                                        "and of the depth-map bands as fp32 to rank 0, per step",
                                                 "ms_per_step": el3 / min(K, 50) * 1e3, "Mrays_per_s": float(c3.item()) * min(K, 50) / el3 / 1e6}
+        if one3 is not None:
+            sec["bands_4k_with_depth_pass_2gpu"]["one_gpu_same_workload_ms"] = one3
+            sec["bands_4k_with_depth_pass_2gpu"]["speedup"] = one3 / (el3 / min(K, 50) * 1e3)
         m3.close()
 
     if rank == 0:
@@ -734,7 +779,10 @@ def run_multi(args) -> None:
                                    else "after the first delivery only the tiles of the previous and the new records are written") + ")",
                        "width": w, "height": h, "poses": N_POSES, "rays_per_step": rays(st), "primary_rays": st["n_pixels"],
                        "shadow_rays": st["n_hit"], "pose_batches_per_rank": len(groups),
-                       "parallelism": f"pose-sharded x{world}, RCCL point-to-point gather of hit tiles to rank 0 on a side stream, overlapped with rendering",
+                       "parallelism": f"pose-sharded x{world}, " + (
+                           "gloo REHEARSAL: ranks share what GPUs there are and every exchange goes through the host (times mean nothing)" if gloo_only
+                           else "RCCL point-to-point gather of hit tiles to rank 0 on a side stream, overlapped with rendering"),
+                       "backend": "gloo" if gloo_only else "nccl (RCCL)",
                        "gather_payload_bytes_per_step": sent_per_step,
                        "dense_rgb8_bytes_per_step_if_not_compacted": 3.0 * w * h * (N_POSES - len(poses_of(N_POSES, 0, world)))},
             "roofline": {"bound": "valu_fp32", "achieved": flops * K / el_g / 1e12, "peak": PEAK_FP32_VALU_TFLOPS * world, "unit": "TFLOP/s",
@@ -746,6 +794,12 @@ def run_multi(args) -> None:
                           "what": "the same poses rendered, frames left on the rank that rendered them"},
             "secondary": sec,
         }
+        if one_gpu_ms is not None:
+            out["one_gpu_same_workload"] = {"ms_per_step": one_gpu_ms, "value": rays(st) / (one_gpu_ms * 1e-3) / 1e6,
+                                            "what": f"the same {N_POSES} poses rendered by rank 0 alone ({min(8, N_POSES)} per rm_blit_poses_device call, "
+                                                    "no gather), measured in this run after the timed legs"}
+            out["speedup"] = one_gpu_ms / (el_g / K * 1e3)
+            out["speedup_no_gather"] = one_gpu_ms / (el_r / K * 1e3)
         if verified is not None:
             out["verified_frames_from_other_ranks"] = verified
         sys.stdout.flush()
@@ -753,6 +807,21 @@ def run_multi(args) -> None:
     mat.close()
     dist.destroy_process_group()
     os.close(real_stdout)
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: starts `python -m torch.distributed.run` with N ranks of this same
+    command line as a CHILD process and returns its exit code.  This process never touches a GPU (it does not even import
+    torch), so nothing that has initialised one is replaced or forked; the ranks' only line on stdout is rank 0's result."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main() -> None:
@@ -774,15 +843,20 @@ def main() -> None:
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="N > 1: gloo = developer rehearsal of the multi-rank code "
                     "path with every exchange through the host (several ranks may then share one GPU: set LOCAL_RANK=0 for all)")
     ap.add_argument("--verify", action="store_true", help="N > 1: rank 0 re-renders one delivered pose per rank and compares the bytes")
+    ap.add_argument("--no-one-gpu-reference", action="store_true", help="N > 1: skip rank 0's untimed rendering of all poses alone "
+                    "(one_gpu_same_workload / speedup in the result line)")
     ap.add_argument("--force-multi", action="store_true", help="developer check: run the N > 1 code path with a single rank")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child:
         pmc_child(args)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, "
+                         "or without WORLD_SIZE in the environment (bench.py then starts its own ranks)")
     if world == 1 and not args.force_multi:
         run_single(args)
     else:

@@ -172,7 +172,15 @@ int rm_blit_steps_device(rm_ctx *ctx, const void *d_src_rgba8, const void *d_sce
  * scene set with rm_set_primitives needs a table in allocated memory and is refused with RM_E_ARG.
  * All contexts on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads)
  * race; issue them in stream order.  The call leaves no event behind, so rm_get_stats after it waits on
- * hip_stream, which must still exist then. */
+ * hip_stream, which must still exist then; and the counters live in the shared array, so rm_get_stats and
+ * rm_debug_counter_slots fail with RM_E_ARG once any later rm_blit_device_noalloc call on that GPU (of this or
+ * another context) has reused it.
+ * Under graph capture (hip_stream is capturing): the call records a memset node that clears the tile-claim counters
+ * and the kernel node, both self-contained -- the launch reads and leaves no frame-to-frame state (the tile queue is
+ * in image order, not ordered by the previous frame's costs), so the graph may be replayed any number of times,
+ * interleaved with direct calls.  Make one direct call on the GPU first: the first call per GPU and per kernel
+ * variant asks the runtime for the array's address and for occupancy figures.  If this context's previous call ran on
+ * another stream, synchronize that stream before capturing (no host-side wait is possible during capture: RM_E_ARG). */
 int rm_blit_device_noalloc(rm_ctx *ctx, const void *d_src_rgba8, const void *d_scene_depth,
                            void *d_dst_rgba8, void *d_dst_depth, void *d_dst_hit,
                            int w, int h, void *hip_stream);
@@ -214,6 +222,13 @@ int rm_shadowmap_directional(rm_ctx *ctx, const float corners[12], const float f
 int rm_shadowmap_directional_device(rm_ctx *ctx, const float corners[12], const float forward[3],
                                     void *d_dst_depth, void *d_dst_hit,
                                     int w, int h, void *hip_stream);
+/* Row-band shard of the same depth pass for multi-GPU rendering: the rows y of the w x h map over the rectangle of
+ * Assets/ShadowMapDirectional.cs:25-34 with (y / band_rows) % n_parts == part, into COMPACT buffers that hold only
+ * those rows in increasing y (rm_band_rows() of them), exactly as rm_blit_bands_device shards the frame.  The bands
+ * of all parts put together are the map rm_shadowmap_directional_device writes, bit for bit. */
+int rm_shadowmap_directional_bands_device(rm_ctx *ctx, const float corners[12], const float forward[3],
+                                          void *d_dst_depth, void *d_dst_hit,
+                                          int w, int h, int band_rows, int part, int n_parts, void *hip_stream);
 
 /* ---- frame transport ------------------------------------------------------
  * No counterpart in the reference (one GPU, no transport).  The blit's alpha is the constant 255

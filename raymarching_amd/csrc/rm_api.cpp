@@ -79,6 +79,7 @@ struct WorkMem {
     uint32_t **partials = nullptr; size_t *partials_cap = nullptr;   // bytes
     unsigned long long *stats = nullptr;
     bool fixed = false;            // static scratch: nothing can grow, sizes beyond capacity are refused
+    bool capturing = false;        // fixed only: the caller's stream is under graph capture, the launch may be replayed any number of times
 };
 
 struct rm_ctx {
@@ -120,6 +121,8 @@ struct rm_ctx {
     bool last_has_event = false;
     uint64_t last_pixels = 0;
     bool have_last = false;
+    bool last_fixed = false;                // the last launch left its counters in the GPU's shared static scratch ...
+    uint64_t last_scratch_gen = 0;          // ... as that scratch's launch number `last_scratch_gen`
 };
 
 namespace {
@@ -373,10 +376,15 @@ int wait_for_last(rm_ctx *c) {
 
 // Orders `stream` behind the context's previous launch, whatever stream that ran on: the queue counters,
 // counter slots, primitive table and view array are shared by consecutive launches.
-int order_after_last(rm_ctx *c, hipStream_t stream) {
+int order_after_last(rm_ctx *c, hipStream_t stream, bool capturing = false) {
     if (!c->have_last) return RM_OK;
     if (c->last_has_event) RM_HIP(c, hipStreamWaitEvent(stream, c->ev_last, 0));
-    else if (c->last_stream != stream) RM_HIP(c, hipStreamSynchronize(c->last_stream));
+    else if (c->last_stream != stream) {
+        // no host-side wait is legal while a stream is being captured
+        if (capturing) return fail(c, RM_E_ARG, "this context's previous call ran on another stream and left no event: "
+                                                "synchronize that stream before capturing a graph on this one");
+        RM_HIP(c, hipStreamSynchronize(c->last_stream));
+    }
     return RM_OK;
 }
 
@@ -628,7 +636,12 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, int family, WorkMem
     if (n_tiles64 > 0x7fffffffull) return fail(c, RM_E_RANGE, "more than 2^31 tiles in one launch: split the pose batch");
     const uint32_t n_tiles = (uint32_t)n_tiles64;
     // the heavy bitmap lives in LDS: keep history only while it fits comfortably beside 4+ blocks per CU
-    bool keep_history = !streamk && n_tiles <= RM_QUEUE_MAX_TILES;
+    // A launch recorded into a graph is replayed with the same arguments any number of times, at moments the host does
+    // not see: it must neither depend on nor advance the frame-to-frame rotation of the counter and heavy-tile sets.
+    // Such a launch is self-contained: its claim counters are cleared in the stream ahead of it (a memset node of the
+    // same graph), it reads no history and appends none, and its kernel leaves every set alone.
+    const bool solo = M.fixed && M.capturing;
+    bool keep_history = !solo && !streamk && n_tiles <= RM_QUEUE_MAX_TILES;
     uint32_t bm_words = keep_history ? (n_tiles + 31) / 32 : 0;
     if (M.fixed && bm_words > S.bm_cap) { keep_history = false; bm_words = 0; }
     RmQueue &Q = P.queue;
@@ -669,13 +682,19 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, int family, WorkMem
     Q.n_tiles = n_tiles; Q.tiles_x = tx; Q.tiles_y = ty;
     Q.tx_magic = ((1ull << 37) + tx - 1) / tx;            // tiles per pose < 2^24, tx <= 4096: (t * magic) >> 37 == t / tx
     const bool same_shape = S.history && S.last_mode == P.mode && S.last_tiles == n_tiles && S.last_tx == tx && S.last_ty == ty;
-    if (S.dirty || (keep_history && !same_shape && !S.zeroed)) {
+    if (solo) {
+        RM_HIP(c, hipMemsetAsync(S.buf, 0, 2 * RM_Q_SHARDS * RM_Q_STRIDE * 4, stream));
+    } else if (S.dirty || (keep_history && !same_shape && !S.zeroed)) {
         // The three bitmap sets were laid out for another tile count, or a launch that kept no history has
         // rotated past them without clearing: start clean.  The stream is already ordered behind the
         // context's previous launch, so the clear needs no host-side wait.
         RM_HIP(c, hipMemsetAsync(S.buf, 0, queue_words(S.bm_cap) * 4, stream));
         S.dirty = false;
         S.history = false;
+    } else if (M.fixed) {
+        // the shared scratch may have been used by a replayed graph since this rotation last saw it: the claim
+        // counters are cleared ahead of every launch (the heavy-tile sets are never touched by a replay)
+        RM_HIP(c, hipMemsetAsync(S.buf, 0, 2 * RM_Q_SHARDS * RM_Q_STRIDE * 4, stream));
     }
     {
         static const uint32_t primes[] = {7919u, 7907u, 7901u, 7883u, 7879u, 7877u, 7873u, 7867u};
@@ -686,13 +705,19 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, int family, WorkMem
     Q.heavy_cap = RM_HEAVY_CAP;
     float thr = getf(c, "_RmHeavyTileThreshold", 24.0f);
     Q.heavy_threshold = keep_history && thr > 0.0f ? (uint32_t)thr : 0xffffffffu;
-    const uint32_t e = ++S.epoch;
-    Q.use_history = (keep_history && getf(c, "_RmTileFeedback", 1.0f) != 0.0f && same_shape) ? 1u : 0u;
-    Q.cnt_cur = e & 1u; Q.cnt_clr = (e + 1u) & 1u;
-    Q.hv_cur = e % 3u; Q.hv_nxt = (e + 1u) % 3u; Q.hv_clr = (e + 2u) % 3u;
-    S.zeroed = false;
-    S.history = keep_history;
-    S.last_mode = P.mode; S.last_tiles = n_tiles; S.last_tx = tx; S.last_ty = ty;
+    if (solo) {
+        Q.use_history = 0u;
+        Q.cnt_cur = 0u; Q.cnt_clr = RM_Q_SOLO;
+        Q.hv_cur = 0u; Q.hv_nxt = 1u; Q.hv_clr = 2u;       // unused: no history is read, appended or cleared
+    } else {
+        const uint32_t e = ++S.epoch;
+        Q.use_history = (keep_history && getf(c, "_RmTileFeedback", 1.0f) != 0.0f && same_shape) ? 1u : 0u;
+        Q.cnt_cur = e & 1u; Q.cnt_clr = (e + 1u) & 1u;
+        Q.hv_cur = e % 3u; Q.hv_nxt = (e + 1u) % 3u; Q.hv_clr = (e + 2u) % 3u;
+        S.zeroed = false;
+        S.history = keep_history;
+        S.last_mode = P.mode; S.last_tiles = n_tiles; S.last_tx = tx; S.last_ty = ty;
+    }
 
     unsigned per_cu = (unsigned)occ_it->second;
     const float cap_per_cu = getf(c, "_RmBlocksPerCU", 0.0f);      // 0: as many as fit
@@ -717,7 +742,7 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, int family, WorkMem
         Q.static_per_wave = (uint32_t)(frac * per_wave);
     }
     int rc = ensure_partials(c, M, blocks * 4);
-    if (rc) { S.dirty = true; return rc; }
+    if (rc) { if (!solo) S.dirty = true; return rc; }
     P.partials = *M.partials;
     {
         // every frame clears the counter set and lists of a later frame: if this launch does not happen,
@@ -725,8 +750,7 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, int family, WorkMem
         hipError_t le = streamk ? rm_launch_stream(P, blocks, stream, nullptr)
                       : fast ? rm_launch_fast(P, blocks, stream, nullptr) : rm_launch_queue(P, blocks, stream, nullptr);
         if (le != hipSuccess) {
-            S.dirty = true;
-            S.history = false;
+            if (!solo) { S.dirty = true; S.history = false; }
             return fail(c, RM_E_DEVICE, std::string("queue kernel launch: ") + hipGetErrorString(le));
         }
     }
@@ -748,6 +772,7 @@ struct DeviceScratch {
     QueueState q;
     uint32_t *partials = nullptr; size_t partials_cap = 0;
     unsigned long long *stats = nullptr;
+    uint64_t generation = 0;       // launches that have used this GPU's scratch so far: whose counters the slots hold
 };
 std::mutex g_scratch_mu;
 DeviceScratch g_scratch[RM_SCRATCH_MAX_DEVICES];
@@ -771,6 +796,17 @@ int device_scratch(rm_ctx *c, DeviceScratch **out) {
         D.ready = true;
     }
     *out = &D;
+    return RM_OK;
+}
+
+// The counters of a launch of the entry point that allocates nothing stay in the GPU's shared scratch only until the
+// next such launch of ANY context on that GPU.
+int scratch_still_ours(rm_ctx *c) {
+    if (!c->have_last || !c->last_fixed) return RM_OK;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (c->device < RM_SCRATCH_MAX_DEVICES && g_scratch[c->device].generation != c->last_scratch_gen)
+        return fail(c, RM_E_ARG, "the static scratch of this GPU has been reused by a later rm_blit_device_noalloc call "
+                                 "(of this or another context): the counters of this context's last call are gone");
     return RM_OK;
 }
 
@@ -800,7 +836,7 @@ int launch(rm_ctx *c, const RmParams &U, hipStream_t stream, WorkMem M, bool rec
     if (U.dom_op != RM_DOM_NONE) kernel = RM_KERNEL_TILE;                                          // and so do the domain operators
     if (U.mode == RM_MODE_FRAG && U.shadow_mode != 0) kernel = RM_KERNEL_TILE;                     // and the shadow-map lookup
     if (U.dst_steps) kernel = RM_KERNEL_TILE;                                                      // and the per-pixel step-count plane
-    int rc = order_after_last(c, stream);
+    int rc = order_after_last(c, stream, M.capturing);
     if (rc) return rc;
     if (kernel != RM_KERNEL_TILE) {
         rc = launch_queue(c, P, stream, kernel, M, forced);
@@ -834,6 +870,7 @@ int launch(rm_ctx *c, const RmParams &U, hipStream_t stream, WorkMem M, bool rec
     c->last_has_event = false;
     c->last_pixels = (uint64_t)U.w * (uint64_t)U.rows * (uint64_t)U.n_poses;
     c->have_last = true;
+    c->last_fixed = M.fixed;
     if (record) {
         RM_HIP(c, hipEventRecord(c->ev_last, stream));
         c->last_has_event = true;
@@ -1085,7 +1122,17 @@ int rm_blit_device_noalloc(rm_ctx *c, const void *d_src, const void *d_sdepth, v
     U.dst_rgba = (uint8_t *)d_rgba; U.dst_depth = (float *)d_depth; U.dst_hit = (uint8_t *)d_hit;
     WorkMem M;
     M.q = &D->q; M.partials = &D->partials; M.partials_cap = &D->partials_cap; M.stats = D->stats; M.fixed = true;
-    return launch(c, U, stream, M, false);
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        M.capturing = cs == hipStreamCaptureStatusActive;
+    }
+    rc = launch(c, U, stream, M, false);
+    if (rc == RM_OK) {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        c->last_scratch_gen = ++D->generation;
+    }
+    return rc;
     RM_CATCH(c)
 }
 
@@ -1187,17 +1234,23 @@ int rm_blit_steps(rm_ctx *c, const uint8_t *src, const float *sdepth, uint8_t *r
 }
 
 static int depth_pass_device(rm_ctx *c, int mode, const float corners[12], const float forward[3],
-                             void *d_depth, void *d_hit, int w, int h, void *hip_stream) {
+                             void *d_depth, void *d_hit, int w, int h, void *hip_stream,
+                             int band_rows = 0, int part = 0, int n_parts = 1) {
     RM_TRY
     int rc = check_size(c, w, h);
     if (rc) return rc;
+    if (band_rows <= 0) { band_rows = h; part = 0; n_parts = 1; }      // the whole map
+    const int rows = rm_band_rows(h, band_rows, part, n_parts);
+    if (rows < 0) return fail(c, RM_E_ARG, "depth pass: bad band arguments");
+    if (rows == 0) return RM_OK;
     DeviceScope ds;
     RM_HIP(c, ds.enter(c->device));
     if ((rc = ensure_device(c))) return rc;
     hipStream_t stream = (hipStream_t)hip_stream;
     RmParams U;
     if ((rc = build_params(c, &U, stream))) return rc;
-    U.w = w; U.h = h; U.rows = h; U.band_rows = h;
+    U.w = w; U.h = h; U.rows = rows;
+    U.band_rows = band_rows; U.part = part; U.n_parts = n_parts;
     U.mode = mode;
     if (mode == RM_MODE_DEPTH_ORTHO) {
         std::memcpy(U.ortho_c, corners, sizeof(float) * 12);
@@ -1245,6 +1298,15 @@ int rm_shadowmap_directional_device(rm_ctx *c, const float corners[12], const fl
     return depth_pass_device(c, RM_MODE_DEPTH_ORTHO, corners, forward, d_depth, d_hit, w, h, hip_stream);
     RM_CATCH(c)
 }
+int rm_shadowmap_directional_bands_device(rm_ctx *c, const float corners[12], const float forward[3], void *d_depth,
+                                          void *d_hit, int w, int h, int band_rows, int part, int n_parts, void *hip_stream) {
+    RM_TRY
+    if (!c) return RM_E_ARG;
+    if (!corners || !forward) return fail(c, RM_E_ARG, "null corners/forward");
+    if (band_rows <= 0) return fail(c, RM_E_ARG, "rm_shadowmap_directional_bands_device: bad band arguments");
+    return depth_pass_device(c, RM_MODE_DEPTH_ORTHO, corners, forward, d_depth, d_hit, w, h, hip_stream, band_rows, part, n_parts);
+    RM_CATCH(c)
+}
 int rm_shadowmap_directional(rm_ctx *c, const float corners[12], const float forward[3], float *depth, int w, int h) {
     RM_TRY
     if (!c) return RM_E_ARG;
@@ -1290,6 +1352,12 @@ int rm_compact_frames_device(rm_ctx *c, const void *d_rgba8, const void *d_hit, 
     if (rc) return rc;
     const unsigned long long tiles = (unsigned long long)((w + 7) / 8) * (unsigned long long)((h + 7) / 8) * (unsigned long long)n_frames;
     if (tiles > 0x7fffffffull) return fail(c, RM_E_RANGE, "rm_compact_frames_device: more than 2^31 tiles in one call");
+    // The records hold the tiles with a hit pixel; everything else is rebuilt from the background.  The step-count term,
+    // getscatter and the light integration along the ray (shader:203,206-212,129-140) also colour miss pixels, so with any
+    // of them set a frame is not "background outside the hit tiles" and the transport would silently lose those pixels.
+    if (getf(c, "_RmStepHeat", 0.0f) != 0.0f || getf(c, "_RmScatter", 0.0f) != 0.0f || getf(c, "_RmVolumetricLight", 0.0f) != 0.0f)
+        return fail(c, RM_E_ARG, "rm_compact_frames_device: _RmStepHeat, _RmScatter and _RmVolumetricLight colour miss pixels too; "
+                                 "such frames are not the background outside their hit tiles (send them whole: rm_pack_rgb_device)");
     DeviceScope ds;
     RM_HIP(c, ds.enter(c->device));
     RM_HIP(c, rm_compact_tiles(d_rgba8, d_hit, w, h, (unsigned)n_frames, d_records, d_count, (hipStream_t)hip_stream));
@@ -1349,8 +1417,9 @@ int rm_debug_counter_slots(rm_ctx *c, uint32_t *out, int max_words, int *words_p
     if (!c || !c->have_last) return fail(c, RM_E_ARG, "rm_debug_counter_slots: no blit has run");
     DeviceScope ds;
     RM_HIP(c, ds.enter(c->device));
-    int rc = wait_for_last(c);
+    int rc = scratch_still_ours(c);
     if (rc) return rc;
+    if ((rc = wait_for_last(c))) return rc;
     size_t words = (size_t)c->last_blocks * rm_slot_words();
     if (words_per_slot) *words_per_slot = (int)rm_slot_words();
     if (n_slots) *n_slots = (int)c->last_blocks;
@@ -1368,6 +1437,10 @@ int rm_get_stats(rm_ctx *c, rm_stats *out) {
     if (!c->have_last) return fail(c, RM_E_ARG, "rm_get_stats: no blit has run");
     DeviceScope ds;
     RM_HIP(c, ds.enter(c->device));
+    {
+        int rc = scratch_still_ours(c);
+        if (rc) return rc;
+    }
     // The reduction runs on the context's own stream, ordered behind the last launch by its event: the stream
     // that launch was given is the caller's and may be gone by now.  A launch of the entry point that
     // allocates nothing leaves no event; its stream is used, and must still exist.

@@ -75,6 +75,7 @@ static_assert(sizeof(RmView) == 64, "RmView layout");
 #define RM_Q_STRIDE 64
 #endif
 //       // words between shard counters: one counter per 256-B line, so shards hit different L2 channels
+#define RM_Q_SOLO 0xffffffffu
 struct RmQueue {
     uint32_t *counters;      // [2][RM_Q_SHARDS][RM_Q_STRIDE] claim counters (first word of each stride)
     uint32_t *heavy_count;   // [3]
@@ -86,11 +87,20 @@ struct RmQueue {
     uint32_t  scatter_mul;       // coprime with n_tiles
     uint32_t  static_per_wave;   // entries every wave without a heavy tile takes without claiming
     uint32_t  use_history;   // 0: previous frame unusable (first frame, size change)
-    uint32_t  cnt_cur, cnt_clr;          // counter sets: in use / cleared for the next frame
+    uint32_t  cnt_cur, cnt_clr;          // counter sets: in use / cleared for the next frame.  cnt_clr == RM_Q_SOLO: a self-contained
+                                         // launch (recorded into a graph): no history read or appended, no set cleared
     uint32_t  hv_cur, hv_nxt, hv_clr;    // heavy sets: read / appended / cleared
     // t / tiles_x for t < 2^24 as (t * tx_magic) >> 37, exact for tiles_x <= 4096 (tx_magic = ceil(2^37 / tiles_x))
     uint64_t  tx_magic;
 };
+
+// words per wave / block in the counter-slot buffer; a timeline build (developer tool) appends start/end timestamps
+// (100 MHz s_memrealtime), the hardware id and the wave's last four tiles
+#ifdef RM_TIMELINE
+#define RM_SLOT_WORDS 16
+#else
+#define RM_SLOT_WORDS 3
+#endif
 
 enum : int32_t { RM_MODE_FRAG = 0, RM_MODE_DEPTH_PERSP = 1, RM_MODE_DEPTH_ORTHO = 2 };
 

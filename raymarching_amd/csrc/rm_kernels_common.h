@@ -25,13 +25,8 @@
 #ifndef RM_HEAVY_DILATE
 #define RM_HEAVY_DILATE 2
 #endif
-// words per block in the counter-slot buffer; a timeline build (developer tool) appends
-// start/end timestamps of the block (100 MHz s_memrealtime) and its hardware id
-#ifdef RM_TIMELINE
-#define RM_SLOT_WORDS 16      // + the wave's last four tiles: start time (10 ns units after the wave's start) and cost << 20 | queue entry
-#else
-#define RM_SLOT_WORDS 3
-#endif
+// (RM_SLOT_WORDS, the words per block in the counter-slot buffer, is defined in rm_device.h; in a timeline build words 8..15
+// are the wave's last four tiles: start time in 10 ns units after the wave's start, and cost << 20 | queue entry)
 #ifdef RM_MIN_WAVES
 #define RM_LB __launch_bounds__(RM_BLOCK, RM_MIN_WAVES)
 #else
@@ -513,10 +508,11 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
     unsigned *bitmap_nxt = Q.bitmaps + (size_t)Q.hv_nxt * Q.bitmap_words;
     unsigned *counters = Q.counters + Q.cnt_cur * RM_Q_SHARDS * RM_Q_STRIDE;
 
-    // frame-to-frame housekeeping: clear what the NEXT frame will append to / claim from
-    if (gw == 0 && lane < RM_Q_SHARDS) Q.counters[(Q.cnt_clr * RM_Q_SHARDS + lane) * RM_Q_STRIDE] = 0u;
-    if (gw == 0 && lane == 0) Q.heavy_count[Q.hv_clr] = 0u;
-    {
+    // frame-to-frame housekeeping: clear what the NEXT frame will append to / claim from (a self-contained launch
+    // takes no part in that rotation: the host clears its counters in the stream ahead of it)
+    if (Q.cnt_clr != RM_Q_SOLO) {
+        if (gw == 0 && lane < RM_Q_SHARDS) Q.counters[(Q.cnt_clr * RM_Q_SHARDS + lane) * RM_Q_STRIDE] = 0u;
+        if (gw == 0 && lane == 0) Q.heavy_count[Q.hv_clr] = 0u;
         unsigned *bitmap_clr = Q.bitmaps + (size_t)Q.hv_clr * Q.bitmap_words;
         for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < Q.bitmap_words; i += gridDim.x * blockDim.x) bitmap_clr[i] = 0u;
     }
@@ -752,7 +748,7 @@ RM_DI void rm_stream_body(const RmParams &U, const S &sc) {
     const unsigned gw = COOP ? blockIdx.x : __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const unsigned n_waves = COOP ? gridDim.x : (gridDim.x * blockDim.x) >> 6;
     unsigned *counter = Q.counters + Q.cnt_cur * RM_Q_SHARDS * RM_Q_STRIDE;
-    if (gw == 0 && writer && lane < RM_Q_SHARDS) Q.counters[(Q.cnt_clr * RM_Q_SHARDS + lane) * RM_Q_STRIDE] = 0u;
+    if (Q.cnt_clr != RM_Q_SOLO && gw == 0 && writer && lane < RM_Q_SHARDS) Q.counters[(Q.cnt_clr * RM_Q_SHARDS + lane) * RM_Q_STRIDE] = 0u;
 
     const float sf = rm_vgpr(U.step_factor), kc = rm_vgpr(.0025f), eps = rm_vgpr(U.nss);
     const V3 L = mk3(rm_vgpr(U.light[0]), rm_vgpr(U.light[1]), rm_vgpr(U.light[2]));

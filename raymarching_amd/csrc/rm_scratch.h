@@ -12,8 +12,9 @@
 // queue state: claim counters and heavy counts (1088 words with 8 counters per set), three heavy lists of 8192 entries,
 // three bitmaps
 #define RM_SCRATCH_QUEUE_BYTES ((size_t)(2u * RM_Q_SHARDS * RM_Q_STRIDE + 64u + 3u * 8192u + 3u * RM_SCRATCH_BM_WORDS) * 4u)
-// counter slots: 32768 slots of three words = one slot per 16x16-pixel block of a 3840x2160 frame (32 400)
-#define RM_SCRATCH_SLOT_BYTES  ((size_t)32768u * 12u)
+// counter slots: 32768 slots of RM_SLOT_WORDS words (three, unless this is a timeline build) = one slot per 16x16-pixel
+// block of a 3840x2160 frame (32 400)
+#define RM_SCRATCH_SLOT_BYTES  ((size_t)32768u * 4u * RM_SLOT_WORDS)
 #define RM_SCRATCH_STATS_BYTES ((size_t)256u)
 #define RM_SCRATCH_BYTES       (RM_SCRATCH_QUEUE_BYTES + RM_SCRATCH_SLOT_BYTES + RM_SCRATCH_STATS_BYTES)
 

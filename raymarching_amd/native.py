@@ -70,6 +70,7 @@ SYMBOLS = [
     ("rm_shadowmap_render_device", C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
     ("rm_shadowmap_directional", C.c_int, [_P, _FP, _FP, _P, C.c_int, C.c_int]),
     ("rm_shadowmap_directional_device", C.c_int, [_P, _FP, _FP, _P, _P, C.c_int, C.c_int, _P]),
+    ("rm_shadowmap_directional_bands_device", C.c_int, [_P, _FP, _FP, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     ("rm_pack_rgb_device", C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     ("rm_unpack_rgb_device", C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     ("rm_tile_record_bytes", C.c_size_t, []),

@@ -83,6 +83,8 @@ public static class RmHip
     [DllImport(Lib)] public static extern int rm_shadowmap_directional(IntPtr ctx, float[] corners12, float[] forward3, IntPtr dstDepth, int w, int h);
     [DllImport(Lib)] public static extern int rm_shadowmap_directional_device(IntPtr ctx, float[] corners12, float[] forward3, IntPtr dDepth, IntPtr dHit,
                                                                               int w, int h, IntPtr hipStream);
+    [DllImport(Lib)] public static extern int rm_shadowmap_directional_bands_device(IntPtr ctx, float[] corners12, float[] forward3, IntPtr dDepth, IntPtr dHit,
+                                                                                    int w, int h, int bandRows, int part, int nParts, IntPtr hipStream);
     [DllImport(Lib)] public static extern int rm_get_stats(IntPtr ctx, out Stats stats);
     [DllImport(Lib)] public static extern int rm_debug_counter_slots(IntPtr ctx, [Out] uint[] words, int maxWords, out int wordsPerSlot, out int nSlots);
     [DllImport(Lib)] public static extern int rm_set_kernel(IntPtr ctx, int variant);

@@ -147,6 +147,12 @@ def test_error_codes_without_gpu_calls():
         odd = C.c_void_p(p.value + 1)
         assert lib.rm_update_frames_device(m.handle, p, 1, p, 1, None, odd, 8, 8, 1, None) == native.RM_E_ARG  # alignment
         assert lib.rm_tile_record_bytes() == 196
+        # frames whose miss pixels are not the background cannot travel as hit tiles only
+        for prop in ("_RmStepHeat", "_RmScatter", "_RmVolumetricLight"):
+            m.SetFloat(prop, 1.0)
+            assert lib.rm_compact_frames_device(m.handle, p, p, 8, 8, 1, p, p, None) == native.RM_E_ARG, prop
+            assert b"miss pixels" in lib.rm_last_error(m.handle)
+            m.SetFloat(prop, 0.0)
         st = native.RmStats()
         assert lib.rm_get_stats(m.handle, C.byref(st)) == native.RM_E_ARG       # nothing rendered yet
     assert lib.rm_set_float(None, b"x", 1.0) == native.RM_E_ARG
@@ -217,4 +223,29 @@ def test_kernels_do_not_spill():
             assert scratch == 0, f"{name} spills {scratch} B"               # (", 0>": the instantiation for any launch shape)"
         elif name.startswith(("rm_queue_kernel4", "rm_tile_kernel", "rm_coop_kernel")):
             # every kernel the automatic choice can pick; the kernels with frag's optional lines carry more state
-            assert scratch <= (128 if "_fx" in name else 96), f"{name} spills {scratch} B"
+            assert scratch <= 128, f"{name} spills {scratch} B"
+
+
+def test_no_scratch_access_inside_the_march_loops():
+    """the bytes above are tolerable only outside the loops: disassembles the 4-slot persistent kernels whose metadata shows
+    scratch and checks that no innermost loop of theirs (the two marches, the normal taps) touches it"""
+    import importlib.util
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    spec = importlib.util.spec_from_file_location("loop_isa", os.path.join(ROOT, "scripts", "loop_isa.py"))
+    li = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(li)
+    if not os.path.exists(os.path.join(li.LLVM, "llvm-objdump")):
+        pytest.skip("no llvm-objdump")
+    import tempfile
+    lib = os.path.join(ROOT, "raymarching_amd", "librmhip.so")
+    for kernel in ("rm_queue_kernel4<rot=1, scl=0>", "rm_queue_kernel4<rot=0, scl=1>", "rm_queue_kernel4_plain<rot=0, scl=0, 1>"):
+        with tempfile.TemporaryDirectory() as d:
+            co, sym = li.find_kernel(lib, kernel, d)
+            assert co is not None, kernel
+            ins, labels = li.disassemble(co, sym)
+        big = [(a, b) for a, b in li.loops(ins, labels) if sum(1 for m, _, _ in ins[a:b + 1] if m.startswith("v_")) >= 40]
+        assert len(big) >= 3, f"{kernel}: expected the two march loops and the tap loop, found {len(big)} loops"
+        for a, b in big:
+            bad = [m for m, _, _ in ins[a:b + 1] if m.startswith("scratch_")]
+            assert not bad, f"{kernel}: {len(bad)} scratch accesses inside the loop at {ins[a][2]}"

@@ -246,6 +246,52 @@ def test_band_shards_reassemble_to_the_full_frame(torch_cuda, w, h, band, parts)
         assert tot == {k: full_stats[k] for k in tot}
 
 
+@pytest.mark.parametrize("name,band,parts,kernel", [("shadow_dir_256x144", 8, 2, 0), ("shadow_dir_256x144", 5, 3, 2),
+                                                    ("shadow_dir_3840x2160", 8, 2, 0), ("shadow_dir_3840x2160", 8, 8, 0)])
+def test_directional_depth_pass_in_bands_reassembles_to_the_full_map(oracle, torch_cuda, name, band, parts, kernel):
+    """the ShadowMapDirectional depth pass rendered as interleaved row bands (rm_shadowmap_directional_bands_device, the
+    multi-GPU decomposition of that pass) equals the one-call map bit for bit, which equals the oracle's (small case) or
+    its committed hashes (4K)"""
+    torch = torch_cuda
+    from raymarching_amd import Material
+    from raymarching_amd.material import _fp, _ptr, current_stream_handle
+    case = cases.BY_NAME[name]
+    w, h = case.w, case.h
+    full = gpu_run(case, torch, kernel=kernel)
+    if name in GOLD and case.heavy:
+        assert sha(full["depth"]) == GOLD[name]["sha_depth"] and sha(full["hit"]) == GOLD[name]["sha_hit"]
+    else:
+        ref = cases.oracle_run(case, oracle)
+        assert np.array_equal(full["depth"].view(np.uint32), ref["depth"].view(np.uint32)) and np.array_equal(full["hit"], ref["hit"])
+    with Material() as mat:
+        mat.set_kernel(kernel)
+        case.bind(mat)
+        c, f = np.ascontiguousarray(case.corners), np.ascontiguousarray(case.forward)
+        out_d = torch.zeros((h, w), dtype=torch.float32, device="cuda:0")
+        out_h = torch.zeros((h, w), dtype=torch.uint8, device="cuda:0")
+        ys = torch.arange(h, device="cuda:0")
+        tot = {"n_hit": 0, "sum_steps_p": 0, "n_pixels": 0}
+        for p in range(parts):
+            rows = mat._lib.rm_band_rows(h, band, p, parts)
+            d = torch.zeros((rows, w), dtype=torch.float32, device="cuda:0")
+            m = torch.zeros((rows, w), dtype=torch.uint8, device="cuda:0")
+            mat._ck(mat._lib.rm_shadowmap_directional_bands_device(mat.handle, _fp(c), _fp(f), _ptr(d), _ptr(m), w, h, band, p, parts,
+                                                                   current_stream_handle("cuda:0")))
+            st = mat.stats()
+            for k in tot:
+                tot[k] += st[k]
+            sel = ((ys // band) % parts) == p
+            out_d[sel], out_h[sel] = d, m
+        torch.cuda.synchronize()
+        assert np.array_equal(out_d.cpu().numpy().view(np.uint32), full["depth"].view(np.uint32))
+        assert np.array_equal(out_h.cpu().numpy(), full["hit"])
+        assert tot == {k: full["stats"][k] for k in tot}
+        lib = mat._lib
+        from raymarching_amd import native
+        assert lib.rm_shadowmap_directional_bands_device(mat.handle, _fp(c), _fp(f), _ptr(out_d), None, w, h, 0, 0, 1, None) == native.RM_E_ARG
+        assert lib.rm_shadowmap_directional_bands_device(mat.handle, _fp(c), _fp(f), _ptr(out_d), None, w, h, 8, 2, 2, None) == native.RM_E_ARG
+
+
 def test_pose_batch_equals_single_blits(oracle, torch_cuda):
     """rm_blit_poses_device over 5 orbit poses == 5 x (SetMatrix x2 + Blit), and pose 3 == the oracle"""
     torch = torch_cuda
