@@ -175,8 +175,8 @@ int rm_blit_steps_device(rm_ctx *ctx, const void *d_src_rgba8, const void *d_sce
  * hip_stream, which must still exist then; and the counters live in the shared array, so rm_get_stats and
  * rm_debug_counter_slots fail with RM_E_ARG once any later rm_blit_device_noalloc call on that GPU (of this or
  * another context) has reused it.
- * Under graph capture (hip_stream is capturing): the call records a memset node that clears the tile-claim counters
- * and the kernel node, both self-contained -- the launch reads and leaves no frame-to-frame state (the tile queue is
+ * Under graph capture (hip_stream is capturing): the call records two kernel nodes, one that clears the tile-claim
+ * counters and the frame's, both self-contained -- the launch reads and leaves no frame-to-frame state (the tile queue is
  * in image order, not ordered by the previous frame's costs), so the graph may be replayed any number of times,
  * interleaved with direct calls.  Make one direct call on the GPU first: the first call per GPU and per kernel
  * variant asks the runtime for the array's address and for occupancy figures.  If this context's previous call ran on

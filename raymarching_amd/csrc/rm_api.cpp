@@ -683,7 +683,7 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, int family, WorkMem
     Q.tx_magic = ((1ull << 37) + tx - 1) / tx;            // tiles per pose < 2^24, tx <= 4096: (t * magic) >> 37 == t / tx
     const bool same_shape = S.history && S.last_mode == P.mode && S.last_tiles == n_tiles && S.last_tx == tx && S.last_ty == ty;
     if (solo) {
-        RM_HIP(c, hipMemsetAsync(S.buf, 0, 2 * RM_Q_SHARDS * RM_Q_STRIDE * 4, stream));
+        RM_HIP(c, rm_zero_words(S.buf, 2 * RM_Q_SHARDS * RM_Q_STRIDE, stream));
     } else if (S.dirty || (keep_history && !same_shape && !S.zeroed)) {
         // The three bitmap sets were laid out for another tile count, or a launch that kept no history has
         // rotated past them without clearing: start clean.  The stream is already ordered behind the
@@ -694,7 +694,7 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, int family, WorkMem
     } else if (M.fixed) {
         // the shared scratch may have been used by a replayed graph since this rotation last saw it: the claim
         // counters are cleared ahead of every launch (the heavy-tile sets are never touched by a replay)
-        RM_HIP(c, hipMemsetAsync(S.buf, 0, 2 * RM_Q_SHARDS * RM_Q_STRIDE * 4, stream));
+        RM_HIP(c, rm_zero_words(S.buf, 2 * RM_Q_SHARDS * RM_Q_STRIDE, stream));
     }
     {
         static const uint32_t primes[] = {7919u, 7907u, 7901u, 7883u, 7879u, 7877u, 7873u, 7867u};

@@ -23,6 +23,13 @@ __global__ __launch_bounds__(1024) void rm_reduce_stats_kernel(const unsigned *_
     if (threadIdx.x < 3) out[threadIdx.x] = s[threadIdx.x];
 }
 
+// clears n 32-bit words: the claim counters of a launch that must not rely on an earlier launch having cleared them.  A
+// kernel rather than a memset so that, recorded into a graph, it is a kernel node ordered like any other launch.
+__global__ __launch_bounds__(256) void rm_zero_words_kernel(uint32_t *__restrict__ p, unsigned n) {
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
 // RGBA8 -> RGB8: the alpha the blit writes is the constant 255 (fixed4(col, 1), shader:214), so a frame
 // that travels over xGMI to the displaying rank carries 3 bytes per pixel.  One thread = 4 pixels:
 // 16 bytes in, 12 bytes out, both as dwords.
@@ -85,6 +92,12 @@ unsigned rm_tile_blocks(int w, int rows, int n_poses) {
 
 hipError_t rm_reduce_stats(const unsigned *partials, unsigned n_blocks, unsigned long long *out, hipStream_t stream) {
     hipLaunchKernelGGL(rm_reduce_stats_kernel, dim3(1), dim3(1024), 0, stream, partials, n_blocks, out);
+    return hipGetLastError();
+}
+
+hipError_t rm_zero_words(void *p, unsigned n_words, hipStream_t stream) {
+    if (n_words == 0) return hipSuccess;
+    hipLaunchKernelGGL(rm_zero_words_kernel, dim3((n_words + 255) / 256), dim3(256), 0, stream, (uint32_t *)p, n_words);
     return hipGetLastError();
 }
 

@@ -33,6 +33,8 @@ hipError_t rm_expand_tiles(const void *records, unsigned n_records, int w, int h
 hipError_t rm_restore_tiles(const void *records, unsigned n_records, int w, int h, unsigned n_frames, const void *src_rgba8, uint32_t bg8,
                             void *rgba, hipStream_t stream);
 hipError_t rm_fill_from_src(const void *src_rgba8, void *dst_rgba8, size_t pixels_per_frame, unsigned n_frames, hipStream_t stream);
+// clears n_words 32-bit words of device memory with a kernel (a kernel node when recorded into a graph)
+hipError_t rm_zero_words(void *p, unsigned n_words, hipStream_t stream);
 hipError_t rm_reduce_stats(const unsigned *partials, unsigned n_blocks, unsigned long long *out, hipStream_t stream);
 
 // persistent tile-queue kernel: `blocks` workgroups of 256 threads.  With blocks_per_cu != nullptr
