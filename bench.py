@@ -35,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_VALU_TFLOPS = 157.3      # MI355X vector fp32 peak: 256 CU x 4 SIMD x 32 lanes x 2 (FMA) x 2 (packed) x 2.4 GHz
+PEAK_VALU_LANE_OPS = 78.6e12       # lane-instructions per second the chip can issue: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
 N_POSES = 64                       # batched-pose configuration: 64 orbit cameras at 7680x4320
 POSE_W, POSE_H = 7680, 4320
 KERNEL_SOURCES = ("rm_kernels_common.h", "rm_math.h", "rm_device.h", "rm_k_queue.hip", "rm_k_tile.hip")
@@ -76,11 +77,12 @@ def pmc_child(args) -> None:
 
 def measure_traffic(w: int, h: int) -> dict:
     """HBM bytes per launch of the frame kernel = FETCH_SIZE + WRITE_SIZE (KB units), each from a rocprofv3 --pmc
-    pass of its own.  The frame reads at most 4 B per lane (no wide loads), so FETCH_SIZE is taken as it reads."""
+    pass of its own.  The frame reads at most 4 B per lane (no wide loads), so FETCH_SIZE is taken as it reads.
+    A third pass counts the kernel's vector instructions (SQ_INSTS_VALU, wave-level) for the issue-rate figure."""
     if shutil.which("rocprofv3") is None:
         return {"error": "rocprofv3 not found"}
     out = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
         d = tempfile.mkdtemp(prefix="rm_pmc_", dir="/tmp")
         try:
             cmd = ["rocprofv3", "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
@@ -99,11 +101,15 @@ def measure_traffic(w: int, h: int) -> dict:
                 con.close()
             if not rows:
                 return {"error": f"no frame kernel in the {counter} pass"}
-            out[counter] = rows[0][1] / max(rows[0][2], 1) * 1024.0
+            out[counter] = rows[0][1] / max(rows[0][2], 1) * (1.0 if counter == "SQ_INSTS_VALU" else 1024.0)
             out["kernel"] = rows[0][0]
         except subprocess.TimeoutExpired:
+            if counter == "SQ_INSTS_VALU" and "WRITE_SIZE" in out:
+                break
             return {"error": f"rocprofv3 --pmc {counter} timed out"}
         except Exception as e:                                   # a profiler problem must not take the benchmark down
+            if counter == "SQ_INSTS_VALU" and "WRITE_SIZE" in out:
+                break
             return {"error": f"{counter}: {type(e).__name__}: {e}"}
         finally:
             shutil.rmtree(d, ignore_errors=True)
@@ -233,12 +239,13 @@ def block(st, ms, extra=None):
 
 # ---- N = 1 -------------------------------------------------------------------------------------------------------------
 def run_single(args) -> None:
-    traffic, traffic_err, traffic_src = None, None, None
+    traffic, traffic_err, traffic_src, valu_insts = None, None, None, None
     if not args.no_traffic:
         t = measure_traffic(args.width, args.height)          # child processes, before this process touches the GPU
         if "bytes" in t:
             traffic, traffic_src = t["bytes"], {"how": "live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over a child run of this frame",
                                                 "kernel": t["kernel"], "fetch_bytes": t["FETCH_SIZE"], "write_bytes": t["WRITE_SIZE"]}
+            valu_insts = t.get("SQ_INSTS_VALU")
         else:
             traffic_err = t["error"]
     if traffic is None:
@@ -302,7 +309,12 @@ def run_single(args) -> None:
                      "sum_steps_p": st["sum_steps_p"], "sum_steps_s": st["sum_steps_s"], "n_hit": st["n_hit"],
                      "sdf_evals_per_s": evals / (kernel_ms * 1e-3),
                      "framebuffer_GBps": (9.0 * st["n_pixels"]) / (kernel_ms * 1e-3) / 1e9,
-                     "kernel_src_sha": kernel_source_sha()},
+                     "kernel_src_sha": kernel_source_sha(),
+                     # what the counters say of the same kernel: wave-level vector instructions x 64 lanes per second, against the
+                     # rate at which the chip can issue them (a wave64 instruction occupies its SIMD-32 for two cycles); this counts
+                     # instructions executed, not the reference's flops, so hoisted uniform work and packed pairs do not flatter it
+                     "valu_insts_per_launch": valu_insts,
+                     "valu_issue_frac": (valu_insts * 64.0 / (kernel_ms * 1e-3) / PEAK_VALU_LANE_OPS) if valu_insts else None},
     }
     props = None
     if not args.no_cpu_baseline:
@@ -475,6 +487,14 @@ def run_single(args) -> None:
                                           "subtrees that provably cannot change a bit of the result)",
                                   "ms_per_step": ms, "Mrays_per_s": rays(s5) / (ms * 1e-3) / 1e6, "flops_per_eval": per_eval,
                                   "tflops": fl5 / (ms * 1e-3) / 1e12, "frac_of_peak": fl5 / (ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS}
+        ls = m5.leaf_stats()
+        leaf_frac = ls["visited"] / max(ls["possible"], 1)
+        sec["stress256_1080p"].update({
+            "executed_leaf_fraction": leaf_frac,
+            "frac_of_peak_executed": sec["stress256_1080p"]["frac_of_peak"] * leaf_frac,
+            "note": "tflops / frac_of_peak count the LITERAL tree (every primitive at every evaluation); the kernel executes "
+                    "executed_leaf_fraction of those leaf evaluations (the rest provably cannot change a bit of the result), so "
+                    "frac_of_peak_executed is the share of peak spent on arithmetic that was actually done"})
         m5.SetFloat("_RmTableSkip", 0.0)                      # the same kernel walking the whole table at every step
         el, ms0 = timed(torch, step5, 3, 1)
         sec["stress256_1080p"]["full_table_walk"] = {"ms_per_step": ms0, "frac_of_peak": fl5 / (ms0 * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS}
@@ -482,16 +502,137 @@ def run_single(args) -> None:
         m5.set_kernel(1)                                      # the exact one-wave-per-tile kernel, for comparison
         el, ms1 = timed(torch, step5, 3, 1)
         sec["stress256_1080p"]["one_wave_per_tile_kernel"] = {"ms_per_step": ms1, "frac_of_peak": fl5 / (ms1 * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS}
-        # the tolerance kernel on the same scene: per-step culling against bounding spheres (frames not bit-equal)
-        for tag, slack, fastm in (("cull_default_slack_strict_math", None, 0.0), ("cull_slack1_fast_math", 1.0, 1.0)):
-            m5.set_kernel(4)
-            m5.SetFloat("_RmCullSlack", -1.0 if slack is None else slack)
-            m5.SetFloat("_RmCullFastMath", fastm)
-            el, msc = timed(torch, step5, 3, 1)
-            sec["stress256_1080p"][tag] = {"ms_per_step": msc, "speedup_vs_exact": ms / msc,
-                                           "frac_of_peak": fl5 / (msc * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS}
         m5.close()
         del f5
+
+
+        # ---- per-launch ramp and tail at the headline size: the same pose 8 times in ONE launch, and two frames in flight ----
+        m9 = default_material(w, h)
+        f9 = Frame(torch, dev, w, h, 8)
+        r9 = Raymarching(scenes.default_camera(w, h), m9, scenes.default_transforms())
+        fc9 = np.ascontiguousarray(np.stack([r9.GetFrustumCorners().m] * 8), dtype=np.float32)
+        cw9 = np.ascontiguousarray(np.stack([r9.cam.cameraToWorldMatrix.m] * 8), dtype=np.float32)
+        ps9 = np.ascontiguousarray(np.stack([r9.cam.transform.position] * 8), dtype=np.float32)
+
+        def step9(_i):
+            blit_poses(m9, fc9, cw9, ps9, f9, w, h, stream)
+
+        el, ms = timed(torch, step9, max(3, Ks // 8), 2, ramp_s=RAMP_S)
+        sec["default_4k_eight_in_one_launch"] = block(st, ms / 8.0, {
+            "what": f"{w}x{h}, the headline pose 8 times in one rm_blit_poses_device launch, per frame: the same arithmetic with one "
+                    "launch ramp and one tail per 8 frames; the difference to the headline is what a launch costs beyond its arithmetic",
+            "launch_overhead_us": (kernel_ms - ms / 8.0) * 1e3})
+        m9b = default_material(w, h)
+        f9b = Frame(torch, dev, w, h)
+        ss9 = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+
+        def step9_pair(_i):
+            mat9a._ck(lib.rm_blit_device(mat9a.handle, None, None, _ptr(fr.color), _ptr(fr.depth), _ptr(fr.hit), w, h, ss9[0].cuda_stream))
+            m9b._ck(lib.rm_blit_device(m9b.handle, None, None, _ptr(f9b.color), _ptr(f9b.depth), _ptr(f9b.hit), w, h, ss9[1].cuda_stream))
+
+        mat9a = default_material(w, h)
+        el, _ = timed(torch, step9_pair, Ks, Ws, ramp_s=RAMP_S)
+        sec["default_4k_two_in_flight"] = {"what": f"{w}x{h}, the headline frame from two contexts on two streams, frames_in_flight 2 (never the headline)",
+                                           "frames_in_flight": 2, "ms_per_frame": el / (2 * Ks) * 1e3,
+                                           "Mrays_per_s": rays(st) * 2 * Ks / el / 1e6,
+                                           "frac_of_peak": flops * 2 * Ks / el / 1e12 / PEAK_FP32_VALU_TFLOPS}
+        m9.close(); m9b.close(); mat9a.close()
+        del f9, f9b
+
+        # ---- the shadow map consumed: depth pass from the light + frame whose shadow term is a lookup (_RmShadowMode 1 / 2) ----
+        from raymarching_amd import ShadowMap
+        from raymarching_amd.unity import Matrix4x4
+        for mode, tag in ((2, "directional"), (1, "perspective")):
+            mf, msm = default_material(w, h), default_material(w, h)       # the frame's material and the depth pass's
+            smap = torch.empty((h, w), dtype=torch.float32, device=dev)
+            if mode == 2:
+                smd2 = ShadowMapDirectional(scenes.light_rectangle(), msm)
+                smd2.Update()
+                cn = np.ascontiguousarray(np.stack(smd2.corners).astype(np.float32).reshape(12))
+                fw = np.ascontiguousarray(smd2.transform.forward.astype(np.float32))
+                kk = Matrix4x4.identity()
+                for i_ in range(4):
+                    kk.SetRow(i_, smd2.corners[i_])
+                mf.SetMatrix("_RmShadowMapCorners", kk)
+                mf.SetVector("_RmShadowMapForward", smd2.transform.forward)
+
+                def depth_pass():
+                    msm._ck(lib.rm_shadowmap_directional_device(msm.handle, _fp(cn), _fp(fw), _ptr(smap), None, w, h, stream))
+            else:
+                lc = scenes.light_camera(w, h)
+                smc = ShadowMap(lc, msm)
+                msm.SetMatrix("_FrustrumCorners", smc.GetFrustumCorners())
+                msm.SetMatrix("_CameraInvViewMatrix", lc.cameraToWorldMatrix)
+                msm.SetVector("_WorldSpaceCameraPos", lc.transform.position)
+                mf.SetMatrix("_ShadowMapVPMatrix", lc.projectionMatrix * lc.worldToCameraMatrix)
+
+                def depth_pass():
+                    msm._ck(lib.rm_shadowmap_render_device(msm.handle, _ptr(smap), None, w, h, stream))
+            mf.SetTexture("_ShadowMap", smap)
+            mf.SetFloat("_RmShadowMode", float(mode))
+
+            def frame_lookup(_i):
+                mf._ck(lib.rm_blit_device(mf.handle, None, None, _ptr(fr.color), _ptr(fr.depth), _ptr(fr.hit), w, h, stream))
+
+            def both(_i):
+                depth_pass()
+                frame_lookup(_i)
+
+            depth_pass()
+            sdp = msm.stats()
+            el, ms_f = timed(torch, frame_lookup, Ks, Ws, ramp_s=RAMP_S)
+            sl = mf.stats()
+            el, ms_b = timed(torch, both, Ks, Ws, ramp_s=RAMP_S)
+            fl_f = 292.0 * sl["sum_steps_p"] + (2152.0 - 9.0 + 30.0) * sl["n_hit"]     # no shadow march; the lookup is ~30 flops per hit pixel
+            sec[f"shadowmap_lookup_{tag}_4k"] = {
+                "what": f"{w}x{h}: the frame with its shadow term looked up in a {w}x{h} {tag} shadow map rendered from the light "
+                        f"(_RmShadowMode {mode}; persistent kernel), instead of the soft-shadow march of the headline",
+                "frame_only_ms": ms_f, "frame_only_frac_of_peak": fl_f / (ms_f * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
+                "depth_pass_plus_frame_ms": ms_b, "headline_frame_with_shadow_march_ms": kernel_ms,
+                "Mrays_per_s_depth_pass_plus_frame": (sl["n_pixels"] + sdp["n_pixels"]) / (ms_b * 1e-3) / 1e6,
+                "primary_evals": sl["sum_steps_p"], "n_hit": sl["n_hit"]}
+            mf.close(); msm.close()
+            del smap
+
+        # ---- the other scene() bodies and one frame with frag's optional lines, 1080p close-ups ---------------------------
+        def closeup_material(body, extra=None):
+            mm = Material(device=0)
+            ts = scenes.default_transforms()
+            Raymarching(scenes.closeup_camera(ts[0].position, 1920, 1080), mm, ts).bind()
+            mm.SetVector("_WorldSpaceLightPos0", scenes.WORLD_SPACE_LIGHT_POS0)
+            mm.SetFloat("_RmSceneBody", float(body))
+            for k_, v_ in (extra or {}).items():
+                mm.SetFloat(k_, v_)
+            return mm
+
+        fb = Frame(torch, dev, 1920, 1080)
+        # literal flops of one evaluation (wrapper 47 + body; a transcendental counts 1): menger has a fixed trip count,
+        # 12 x (3 swaps + euler rotate 45 + 6 + 2) + 8 = 680 distance-only, + 12 x 30 for the orbit traps
+        bodies = (("menger_closeup_1080p", 1, None, 47 + 680, 47 + 1040, "exact: fixed 12 iterations"),
+                  ("mandelbulb_closeup_1080p", 3, None, 47 + 12 * 32 + 5, 47 + 12 * 62 + 5,
+                   "UPPER BOUND: 12 iterations counted, the loop leaves early once r > 10 (the kernel does not count iterations)"),
+                  ("fx_bounce_step_heat_1080p", 0, {"_RmBounce": 1.0, "_RmStepHeat": 1.0}, 281, 389, "exact (counters are the camera ray's: the bounce march is not counted)"))
+        for tag, body, extra, fw_, ff_, how in bodies:
+            if body == 0:
+                mm = default_material(1920, 1080)
+                for k_, v_ in extra.items():
+                    mm.SetFloat(k_, v_)
+            else:
+                mm = closeup_material(body, extra)
+
+            def stepb(_i, mm=mm):
+                mm._ck(lib.rm_blit_device(mm.handle, None, None, _ptr(fb.color), _ptr(fb.depth), _ptr(fb.hit), 1920, 1080, stream))
+
+            el, ms = timed(torch, stepb, 10, 2)
+            sb = mm.stats()
+            evals_b = sb["sum_steps_p"] + sb["sum_steps_s"] + 7 * sb["n_hit"]
+            flb = (fw_ + 11.0) * sb["sum_steps_p"] + (fw_ + 14.0) * sb["sum_steps_s"] + sb["n_hit"] * (6.0 * fw_ + ff_ + 77.0)
+            sec[tag] = {"what": f"1920x1080, _RmSceneBody {body}" + (f", {extra}" if extra else "") + " (tile kernels)",
+                        "ms_per_step": ms, "Mrays_per_s": rays(sb) / (ms * 1e-3) / 1e6, "sdf_evals_per_s": evals_b / (ms * 1e-3),
+                        "flops_per_eval_distance_only": fw_, "flop_count": how,
+                        "tflops": flb / (ms * 1e-3) / 1e12, "frac_of_peak": flb / (ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS}
+            mm.close()
+        del fb
 
         # ---- 64 orbit poses at 7680x4320 on this one GPU: the N = 1 point of the strong-scaling curve ----------------
         m6 = default_material(POSE_W, POSE_H)

@@ -265,6 +265,11 @@ int rm_update_frames_device(rm_ctx *ctx, const void *d_old_records, uint32_t n_o
  * step-count heat map, Assets/Raymarching.shader:203).  rm_get_stats waits for
  * the stream of the last call and returns that call's counters. */
 int rm_get_stats(rm_ctx *ctx, rm_stats *out);
+/* What the exact culling of the table kernels saved in the last call (no counterpart in the reference): *visited = leaf
+ * (primitive) evaluations the waves executed, *possible = the evaluations a walk of the whole table at every scene
+ * evaluation would have executed, both summed over the waves of the call.  RM_E_ARG unless the last call ran the table
+ * kernel with exact culling (tables of 33 to 512 primitives, _RmTableSkip not 0, none of frag's optional lines). */
+int rm_get_leaf_stats(rm_ctx *ctx, uint64_t *visited, uint64_t *possible);
 /* Developer aid, no counterpart in the reference: copies the raw per-workgroup counter
  * slots of the last call (words_per_slot 32-bit words each: hit pixels, primary
  * evaluations, shadow evaluations, then build-specific words) to host memory. */
@@ -274,8 +279,8 @@ int rm_debug_counter_slots(rm_ctx *ctx, uint32_t *out, int max_words, int *words
  * refill, 5 four waves per tile that split the primitive table (tables of 3 to 512 primitives; others take 1; tables of 33 to 512
  * primitives, from 65 with op bits, also skip the subtrees that cannot change a bit of a march step's result, unless the
  * float property _RmTableSkip is 0).  4 = the
- * opt-in tolerance kernels (fused multiply-adds and hardware sqrt/rcp in the march loops; per-step culling for
- * smooth-union tables): frames within the port's tolerance, not bit-identical. */
+ * opt-in tolerance kernel for the reference's 4-slot scene (fused multiply-adds and hardware sqrt/rcp in the two march
+ * loops): frames within the port's tolerance, not bit-identical; every other scene is rendered by the exact kernels. */
 int rm_set_kernel(rm_ctx *ctx, int variant);
 
 /* Unity's native-plugin loader calls these two, if a plugin exports them, when it loads and unloads the

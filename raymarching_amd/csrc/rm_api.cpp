@@ -102,6 +102,8 @@ struct rm_ctx {
     uint32_t *d_partials = nullptr; size_t d_partials_cap = 0;   // per-block counter slots of the last launch
     RmPrimDev *d_prims = nullptr;  size_t d_prims_cap = 0;
     RmView *d_views = nullptr;     size_t d_views_cap = 0;
+    uint32_t *d_leaf_stats = nullptr; size_t d_leaf_stats_cap = 0;   // per wave of the exact-culling table kernel: leaves visited / possible
+    unsigned last_leaf_waves = 0;  // waves of the last launch that wrote leaf statistics (0: it was no culling launch)
     void *d_stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // src, sdepth, rgba, depth, hit, steps
     size_t d_stage_cap[6] = {0, 0, 0, 0, 0, 0};
 
@@ -468,28 +470,8 @@ int build_params(rm_ctx *c, RmParams *U, hipStream_t stream) {
             U->tail_ops = tail;
             flags |= RM_SF_CSG;
         }
-        // behind the table: a bounding sphere per primitive and its scale ratio, for the tolerance kernel's culling
-        const size_t extra16 = n + (n + 3) / 4;
         if (c->prims_dirty || !c->d_prims) {
-            std::vector<float> extra(extra16 * 4, 0.0f);
-            for (size_t i = 0; i < n; i++) {
-                const rm_primitive &p = c->prims[i];
-                float rl;                                          // radius about the local origin that holds the primitive
-                switch (p.type) {
-                case RM_SPHERE:   rl = std::fabs(p.params[0]) * .5f; break;
-                case RM_BOX:      rl = .5f * std::sqrt(p.params[0] * p.params[0] + p.params[1] * p.params[1] + p.params[2] * p.params[2]); break;
-                case RM_LINK:     rl = std::fabs(p.params[0]) + std::fabs(p.params[1]) + std::fabs(p.params[2]); break;
-                case RM_CYLINDER: rl = std::sqrt(p.params[0] * p.params[0] + p.params[1] * p.params[1]); break;
-                default:          rl = std::fabs(p.params[0]) + std::fabs(p.params[1]); break;
-                }
-                const float sx = std::fabs(p.scale[0]), sy = std::fabs(p.scale[1]), sz = std::fabs(p.scale[2]);
-                const float smax = std::fmax(sx, std::fmax(sy, sz)), smin = std::fmin(sx, std::fmin(sy, sz));
-                extra[4 * i + 0] = p.pos[0]; extra[4 * i + 1] = p.pos[1]; extra[4 * i + 2] = p.pos[2];
-                extra[4 * i + 3] = rl * smax * 1.0001f;
-                const float ratio = smax / smin;
-                extra[4 * n + i] = (std::isfinite(ratio) && ratio >= 1.0f) ? ratio * 1.0001f : __builtin_inff();   // inf: never culled
-            }
-            const size_t bytes = n * sizeof(RmPrimDev) + extra16 * 16;
+            const size_t bytes = n * sizeof(RmPrimDev);
             int rc = ensure_cap(c, (uint8_t **)&c->d_prims, &c->d_prims_cap, bytes);
             if (rc) return rc;
             // the table must be in place before any later launch reads it, and the
@@ -497,22 +479,11 @@ int build_params(rm_ctx *c, RmParams *U, hipStream_t stream) {
             // after every earlier launch (on whatever stream) has finished with the old table
             if ((rc = wait_for_last(c))) return rc;
             RM_HIP(c, hipMemcpy(c->d_prims, t.data(), n * sizeof(RmPrimDev), hipMemcpyHostToDevice));
-            RM_HIP(c, hipMemcpy((uint8_t *)c->d_prims + n * sizeof(RmPrimDev), extra.data(), extra16 * 16, hipMemcpyHostToDevice));
             c->prims_dirty = false;
         }
         U->prim_table = c->d_prims;
         U->n_prims = (int)n;
         U->lds_prims = (n <= RM_LDS_PRIMS && getf(c, "_RmLdsTable", 1.0f) != 0.0f) ? (int)n : 0;
-        U->cull_extra16 = (int32_t)extra16;
-        U->cull_fast_math = getf(c, "_RmCullFastMath", 0.0f) != 0.0f ? 1 : 0;
-        {
-            // default slack: k * tree depth, the bound under which a skipped leaf provably cannot reach the root
-            int depth = 0;
-            while (((size_t)1 << depth) < n) depth++;
-            const float dflt = 0.5f * (float)depth + 0.01f;
-            const float user = getf(c, "_RmCullSlack", -1.0f);
-            U->cull_slack = user >= 0.0f ? user : dflt;
-        }
     }
     const int body = (int)getf(c, "_RmSceneBody", 0.0f);
     if (body != RM_BODY_PRIMS) {
@@ -655,7 +626,7 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, int family, WorkMem
         return fail(c, RM_E_RANGE, "the persistent kernel's tile bitmap and primitive table do not fit one workgroup's LDS for this frame");
     }
     const int vi = rm_variant_index(P), tab = P.n_prims > 0 ? 1 : 0;
-    const uint64_t occ_key = ((uint64_t)(streamk ? 1 : (fast ? 8 : 4) + rm_queue_shape(P)) << 60) | ((uint64_t)vi << 52) | ((uint64_t)tab << 48) | (uint64_t)lds_bytes;
+    const uint64_t occ_key = ((uint64_t)(streamk ? 1 : fast ? 2 : 3) << 60) | ((uint64_t)rm_queue_shape(P) << 56) | ((uint64_t)vi << 52) | ((uint64_t)tab << 48) | (uint64_t)lds_bytes;
     auto occ_it = c->occ.find(occ_key);
     if (occ_it == c->occ.end()) {
         int o[2] = {0, 0};
@@ -825,20 +796,20 @@ int launch(rm_ctx *c, const RmParams &U, hipStream_t stream, WorkMem M, bool rec
                : ((U.n_prims > 0 || U.body != RM_BODY_PRIMS || U.mode != RM_MODE_FRAG) ? RM_KERNEL_TILE : RM_KERNEL_QUEUE);
     if (kernel == RM_KERNEL_COOP) kernel = RM_KERNEL_TILE;       // a tile kernel: the cooperative one where it applies (below)
     // the tolerance kernel exists for the reference's 4-slot scene only; anything else takes the automatic (exact) choice
-    bool cull = false;
     if (kernel == RM_KERNEL_FAST && (U.n_prims > 0 || U.body != RM_BODY_PRIMS)) {
-        // table scenes that are plain smooth unions and fit the LDS table get the culling kernel
-        cull = U.body == RM_BODY_PRIMS && U.n_prims > 0 && U.lds_prims == U.n_prims && !(U.scene_flags & RM_SF_CSG);
         kernel = (U.n_prims > 0 || U.body != RM_BODY_PRIMS || U.mode != RM_MODE_FRAG) ? RM_KERNEL_TILE : RM_KERNEL_QUEUE;
     }
     if (U.body != RM_BODY_PRIMS && kernel == RM_KERNEL_STREAM) kernel = RM_KERNEL_QUEUE;      // no stream kernel for the fractal bodies
     if (U.mode == RM_MODE_FRAG && (U.fx_flags != 0 || U.fx_view != 0 || U.light_model != 0)) kernel = RM_KERNEL_TILE;   // the optional frag lines exist in the tile kernels only
     if (U.dom_op != RM_DOM_NONE) kernel = RM_KERNEL_TILE;                                          // and so do the domain operators
-    if (U.mode == RM_MODE_FRAG && U.shadow_mode != 0) kernel = RM_KERNEL_TILE;                     // and the shadow-map lookup
+    // the shadow-map lookup: the persistent kernel has it for the plain frame (4-slot scene, whole frame, no source image or
+    // depth texture), everything else takes the tile kernels with the optional lines
+    if (U.mode == RM_MODE_FRAG && U.shadow_mode != 0 && !(kernel == RM_KERNEL_QUEUE && rm_queue_shape(P) == 4)) kernel = RM_KERNEL_TILE;
     if (U.dst_steps) kernel = RM_KERNEL_TILE;                                                      // and the per-pixel step-count plane
     int rc = order_after_last(c, stream, M.capturing);
     if (rc) return rc;
     if (kernel != RM_KERNEL_TILE) {
+        c->last_leaf_waves = 0;
         rc = launch_queue(c, P, stream, kernel, M, forced);
         if (rc == RM_FALLBACK_TILE) kernel = RM_KERNEL_TILE;
         else if (rc) return rc;
@@ -849,7 +820,7 @@ int launch(rm_ctx *c, const RmParams &U, hipStream_t stream, WorkMem M, bool rec
         // tables: the four waves of a block share one 8x8 tile and split the table (same bits, waves that finish
         // together, a four times shorter critical chain), with or without frag's optional lines; rm_set_kernel(1) keeps
         // the one-wave-per-tile kernels
-        const bool coop = !(cull && plain) && c->kernel != RM_KERNEL_TILE && U.body == RM_BODY_PRIMS &&
+        const bool coop = c->kernel != RM_KERNEL_TILE && U.body == RM_BODY_PRIMS &&
                           U.n_prims >= RM_COOP_MIN_PRIMS && U.lds_prims == U.n_prims;
         unsigned n_blocks = coop ? rm_coop_blocks(U.w, U.rows, U.n_poses) : rm_tile_blocks(U.w, U.rows, U.n_poses);
         rc = ensure_partials(c, M, n_blocks);
@@ -858,8 +829,16 @@ int launch(rm_ctx *c, const RmParams &U, hipStream_t stream, WorkMem M, bool rec
         // tables of 33 to 512 primitives (from 65 with op bits): the shared tile with exact culling in the marches (same bits;
         // _RmTableSkip 0 keeps the full table walk)
         const bool skip = coop && plain && rm_skip_applies(P) && getf(c, "_RmTableSkip", 1.0f) != 0.0f;
-        if (cull && plain) RM_HIP(c, rm_launch_cull_tiles(P, stream));
-        else if (skip) RM_HIP(c, rm_launch_coop_skip_tiles(P, stream));
+        c->last_leaf_waves = 0;
+        if (skip && !M.fixed) {
+            // what the culling saved, for rm_get_leaf_stats: two words per wave
+            const size_t bytes = (size_t)n_blocks * 4 * 2 * sizeof(uint32_t);
+            if (bytes > c->d_leaf_stats_cap && (rc = wait_for_last(c))) return rc;
+            if ((rc = ensure_cap(c, &c->d_leaf_stats, &c->d_leaf_stats_cap, bytes))) return rc;
+            P.leaf_stats = c->d_leaf_stats;
+            c->last_leaf_waves = n_blocks * 4;
+        }
+        if (skip) RM_HIP(c, rm_launch_coop_skip_tiles(P, stream));
         else if (coop) RM_HIP(c, rm_launch_coop_tiles(P, stream));
         else RM_HIP(c, rm_launch_tiles(P, stream));
         c->last_blocks = n_blocks;
@@ -915,6 +894,7 @@ void rm_destroy(rm_ctx *c) {
         for (int i = 0; i < 6; i++) if (c->d_stage[i]) (void)hipFree(c->d_stage[i]);
         if (c->d_prims) (void)hipFree(c->d_prims);
         if (c->d_views) (void)hipFree(c->d_views);
+        if (c->d_leaf_stats) (void)hipFree(c->d_leaf_stats);
         if (c->d_stats) (void)hipFree(c->d_stats);
         if (c->d_partials) (void)hipFree(c->d_partials);
         if (c->q.buf) (void)hipFree(c->q.buf);
@@ -1427,6 +1407,25 @@ int rm_debug_counter_slots(rm_ctx *c, uint32_t *out, int max_words, int *words_p
         if (words > (size_t)max_words) words = (size_t)max_words;
         RM_HIP(c, hipMemcpy(out, c->last_partials, words * 4, hipMemcpyDeviceToHost));
     }
+    return RM_OK;
+    RM_CATCH(c)
+}
+
+int rm_get_leaf_stats(rm_ctx *c, uint64_t *visited, uint64_t *possible) {
+    RM_TRY
+    if (!c || !visited || !possible) return fail(c, RM_E_ARG, "rm_get_leaf_stats: null argument");
+    *visited = *possible = 0;
+    if (!c->have_last || c->last_leaf_waves == 0)
+        return fail(c, RM_E_ARG, "rm_get_leaf_stats: the last call did not run the table kernel with exact culling");
+    DeviceScope ds;
+    RM_HIP(c, ds.enter(c->device));
+    int rc = wait_for_last(c);
+    if (rc) return rc;
+    std::vector<uint32_t> h((size_t)c->last_leaf_waves * 2);
+    RM_HIP(c, hipMemcpy(h.data(), c->d_leaf_stats, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    uint64_t v = 0, p = 0;
+    for (size_t i = 0; i < h.size(); i += 2) { v += h[i]; p += h[i + 1]; }
+    *visited = v; *possible = p;
     return RM_OK;
     RM_CATCH(c)
 }

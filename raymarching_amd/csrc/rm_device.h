@@ -127,9 +127,6 @@ struct RmParams {
     int32_t  n_prims;          // 0: prims4 below
     int32_t  lds_prims;        // n_prims if the table is staged in LDS by each workgroup, else 0
     int32_t  scene_flags;
-    int32_t  cull_extra16;     // 16-byte words behind the table in prim_table: n float4 bounding spheres, then n floats max/min scale
-    int32_t  cull_fast_math;   // 1: the culled evaluation also uses the fast arithmetic of the 4-slot tolerance kernel
-    float    cull_slack;       // how far above the root's upper bound a leaf's lower bound must lie to be skipped (tolerance kernel)
     uint32_t tail_ops;       // bit l: the final merge with stack level l is smax (see SceneN::tree)
     const RmView    *views;    // n_poses views, or nullptr
     const RmPrimDev *prim_table;
@@ -141,6 +138,8 @@ struct RmParams {
     uint32_t *dst_steps;       // optional, tile kernels only: per pixel, scene() evaluations of the primary march (low 16 bits,
                                // ray.steps of cginc:37,387 counted in evaluations) and of the shadow march (high 16 bits)
     uint32_t *partials;        // counter slots (per block or per wave): n_hit, primary evals, shadow evals
+    uint32_t *leaf_stats;      // optional, exact-culling table kernel only: per wave two words, leaf evaluations executed and
+                               // leaf evaluations a full table walk would have executed
     RmQueue   queue;           // persistent kernel only
     RmPrimDev prims4[4];
     // fractal scene() bodies (cginc:264-313); the wrapper transform is prims4[0]

@@ -31,6 +31,7 @@ hipError_t launch_fast_variant(const RmParams &U, unsigned blocks, hipStream_t s
     if (shape == 1) return launch_fast_shape<ROT, SCL, 1>(U, blocks, stream, blocks_per_cu);
     if (shape == 2) return launch_fast_shape<ROT, SCL, 2>(U, blocks, stream, blocks_per_cu);
     if (shape == 3) return launch_fast_shape<ROT, SCL, 3>(U, blocks, stream, blocks_per_cu);
+    // (shape 4, the shadow-map lookup, is never routed here)
     return launch_fast_shape<ROT, SCL, 0>(U, blocks, stream, blocks_per_cu);
 }
 

@@ -39,6 +39,7 @@ hipError_t launch_queue_variant(const RmParams &U, unsigned blocks, hipStream_t 
         hipError_t e = shape == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, rm_queue_kernel4_plain<ROT, SCL, 1>, 256, lds4)
                      : shape == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, rm_queue_kernel4_plain<ROT, SCL, 3>, 256, lds4)
                      : shape == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, rm_queue_kernel4_plain<ROT, SCL, 2>, 256, lds4)
+                     : shape == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, rm_queue_kernel4_plain<ROT, SCL, 4>, 256, lds4)
                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, rm_queue_kernel4<ROT, SCL>, 256, lds4);
         if (e != hipSuccess) return e;
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nN, rm_queue_kernelN<ROT, SCL>, 256, (size_t)((U.queue.bitmap_words + 3u) & ~3u) * 4 + (size_t)U.lds_prims * sizeof(RmPrimDev));
@@ -51,6 +52,7 @@ hipError_t launch_queue_variant(const RmParams &U, unsigned blocks, hipStream_t 
     else if (shape == 1) hipLaunchKernelGGL((rm_queue_kernel4_plain<ROT, SCL, 1>), dim3(blocks), dim3(256), lds, stream, U);
     else if (shape == 2) hipLaunchKernelGGL((rm_queue_kernel4_plain<ROT, SCL, 2>), dim3(blocks), dim3(256), lds, stream, U);
     else if (shape == 3) hipLaunchKernelGGL((rm_queue_kernel4_plain<ROT, SCL, 3>), dim3(blocks), dim3(256), lds, stream, U);
+    else if (shape == 4) hipLaunchKernelGGL((rm_queue_kernel4_plain<ROT, SCL, 4>), dim3(blocks), dim3(256), lds, stream, U);
     else               hipLaunchKernelGGL((rm_queue_kernel4<ROT, SCL>), dim3(blocks), dim3(256), lds, stream, U);
     return hipGetLastError();
 }
@@ -62,6 +64,7 @@ int rm_queue_shape(const RmParams &U) {
                       U.dst_rgba && U.dst_depth && U.dst_hit && U.inv_w != 0.0f && U.inv_h != 0.0f;
     if (!base) return 0;
     const bool single = !U.views && U.n_poses == 1;
+    if (U.shadow_mode != 0) return (single && !U.src && !U.sdepth && U.shadow_map) ? 4 : 0;
     if (!U.src && !U.sdepth) return single ? 1 : (U.views ? 2 : 0);
     if (U.src && U.sdepth && single) return 3;
     return 0;

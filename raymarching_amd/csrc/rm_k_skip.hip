@@ -31,6 +31,11 @@ __global__ __launch_bounds__(256, CSG ? 4 : RM_SKIP_WAVES) void rm_coop_kernelN_
     const bool in_bounds = x < U.w && yl < U.rows;
     PixelOut po = rmx::compute_pixel(U, sc, coop, in_bounds ? x : U.w - 1, in_bounds ? yl : U.rows - 1, (int)blockIdx.z, in_bounds,
                                      c_hit, c_p, c_s);
+    if (U.leaf_stats && lane == 0) {
+        const unsigned bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        U.leaf_stats[(bid * 4u + wv) * 2u] = sc.n_visited;
+        U.leaf_stats[(bid * 4u + wv) * 2u + 1u] = sc.n_possible;
+    }
     if (wv == 0) {
         if (in_bounds) rm_store_pixel(U, po);                             // the four waves hold the same pixels
         c_hit = rm_wave_sum(c_hit); c_p = rm_wave_sum(c_p); c_s = rm_wave_sum(c_s);

@@ -134,7 +134,7 @@ RM_DI void rm_setup_ray(const RmParams &U, int x, int yl, int pose, V3 &ro, V3 &
         rd = mk3(U.ortho_fwd[0], U.ortho_fwd[1], U.ortho_fwd[2]);
     } else {
         // rasteriser interpolation of vert's viewDir (cginc:26-33) to the pixel centre
-        if (SHAPE == 1 || SHAPE == 3 || (!PLAIN && use_sv)) {
+        if (SHAPE == 1 || SHAPE == 3 || SHAPE == 4 || (!PLAIN && use_sv)) {
             typedef float rm_f4 __attribute__((ext_vector_type(4)));
             const volatile RM_LDS rm_f4 *q = (const volatile RM_LDS rm_f4 *)sv;      // four ds_read_b128, one wait
             const rm_f4 a = q[0], b = q[1], c = q[2], d = q[3];
@@ -152,6 +152,35 @@ RM_DI void rm_setup_ray(const RmParams &U, int x, int yl, int pose, V3 &ro, V3 &
     depth = U.far_plane;                                          // shader:154
     if (SHAPE == 3 || (!PLAIN && U.mode == RM_MODE_FRAG && U.sdepth)) depth = U.sdepth[gidx];
     depth = fminf(depth, U.max_dist);                             // cginc:368
+}
+
+
+// Shadow-map lookup that takes getshadow()'s place when U.shadow_mode != 0: 1 = lit, 0 = in shadow.  q is the point
+// getshadow() would start from (shader:107).  Perspective map: c = mul(_ShadowMapVPMatrix, float4(q,1)), uv = c.xy/c.w*.5+.5,
+// eye depth c.w against the stored r.length; directional map: coordinates along the rectangle's edges and its forward.
+RM_DI float rm_shadow_lookup(const RmParams &U, V3 p, V3 n, float contact) {
+    const V3 q = mk3(p.x + (n.x * contact) * 2.0f, p.y + (n.y * contact) * 2.0f, p.z + (n.z * contact) * 2.0f);
+    float uu, vv, d;
+    if (U.shadow_mode == 1) {
+        const float cx = ((U.sm_row0[0] * q.x + U.sm_row0[1] * q.y) + U.sm_row0[2] * q.z) + U.sm_row0[3];
+        const float cy = ((U.sm_row1[0] * q.x + U.sm_row1[1] * q.y) + U.sm_row1[2] * q.z) + U.sm_row1[3];
+        const float cw = ((U.sm_row3[0] * q.x + U.sm_row3[1] * q.y) + U.sm_row3[2] * q.z) + U.sm_row3[3];
+        if (!(cw > 0.0f)) return 1.0f;
+        uu = (cx / cw) * .5f + .5f;
+        vv = (cy / cw) * .5f + .5f;
+        d = cw;
+    } else {
+        const V3 r = mk3(q.x - U.sm_bl[0], q.y - U.sm_bl[1], q.z - U.sm_bl[2]);
+        uu = rm_dot3(r, mk3(U.sm_e1[0], U.sm_e1[1], U.sm_e1[2])) / U.sm_n1;
+        vv = rm_dot3(r, mk3(U.sm_e2[0], U.sm_e2[1], U.sm_e2[2])) / U.sm_n2;
+        d = rm_dot3(r, mk3(U.sm_fwd[0], U.sm_fwd[1], U.sm_fwd[2]));
+    }
+    if (!(uu >= 0.0f && uu < 1.0f && vv >= 0.0f && vv < 1.0f)) return 1.0f;
+    int ix = (int)floorf(uu * (float)U.sm_w), iy = (int)floorf(vv * (float)U.sm_h);
+    ix = ix > U.sm_w - 1 ? U.sm_w - 1 : ix;
+    iy = iy > U.sm_h - 1 ? U.sm_h - 1 : iy;
+    const float stored = U.shadow_map[(size_t)iy * (size_t)U.sm_w + (size_t)ix];
+    return d > stored * U.sm_onebias ? 0.0f : 1.0f;
 }
 
 
@@ -196,7 +225,9 @@ RM_DI PixelOut rm_compute_pixel(const RmParams &U, const S &sc, int x, int yl, i
             V3 n = rm_normalize(raw);
             V4 s = sc.full(hp);                                                                   // shader:193
             int sev = 0;
-            float sh = rm_getshadow(sc, hp, n, L, r.contact, U.shadow_depth, U.n_steps, sf, sev);
+            float sh;
+            if (rm_shape<S>::value == 4) sh = rm_shadow_lookup(U, hp, n, r.contact);       // the bound _ShadowMap answers instead of the march
+            else sh = rm_getshadow(sc, hp, n, L, r.contact, U.shadow_depth, U.n_steps, sf, sev);
             c_s += (unsigned)sev;
             float shadow = sh * 0.75f + .25f;                        // remap(x,0,1,.25,1), cginc:80-82
             float ndl = rm_dot3(n, L) * .5f + .5f;
@@ -264,34 +295,6 @@ RM_DI V3 rm_normal_raw(const RmParams &U, const S &sc, V3 hp) {
         raw.x = a == 0 ? d : raw.x; raw.y = a == 1 ? d : raw.y; raw.z = a == 2 ? d : raw.z;
     }
     return raw;
-}
-
-// Shadow-map lookup that takes getshadow()'s place when U.shadow_mode != 0: 1 = lit, 0 = in shadow.  q is the point
-// getshadow() would start from (shader:107).  Perspective map: c = mul(_ShadowMapVPMatrix, float4(q,1)), uv = c.xy/c.w*.5+.5,
-// eye depth c.w against the stored r.length; directional map: coordinates along the rectangle's edges and its forward.
-RM_DI float rm_shadow_lookup(const RmParams &U, V3 p, V3 n, float contact) {
-    const V3 q = mk3(p.x + (n.x * contact) * 2.0f, p.y + (n.y * contact) * 2.0f, p.z + (n.z * contact) * 2.0f);
-    float uu, vv, d;
-    if (U.shadow_mode == 1) {
-        const float cx = ((U.sm_row0[0] * q.x + U.sm_row0[1] * q.y) + U.sm_row0[2] * q.z) + U.sm_row0[3];
-        const float cy = ((U.sm_row1[0] * q.x + U.sm_row1[1] * q.y) + U.sm_row1[2] * q.z) + U.sm_row1[3];
-        const float cw = ((U.sm_row3[0] * q.x + U.sm_row3[1] * q.y) + U.sm_row3[2] * q.z) + U.sm_row3[3];
-        if (!(cw > 0.0f)) return 1.0f;
-        uu = (cx / cw) * .5f + .5f;
-        vv = (cy / cw) * .5f + .5f;
-        d = cw;
-    } else {
-        const V3 r = mk3(q.x - U.sm_bl[0], q.y - U.sm_bl[1], q.z - U.sm_bl[2]);
-        uu = rm_dot3(r, mk3(U.sm_e1[0], U.sm_e1[1], U.sm_e1[2])) / U.sm_n1;
-        vv = rm_dot3(r, mk3(U.sm_e2[0], U.sm_e2[1], U.sm_e2[2])) / U.sm_n2;
-        d = rm_dot3(r, mk3(U.sm_fwd[0], U.sm_fwd[1], U.sm_fwd[2]));
-    }
-    if (!(uu >= 0.0f && uu < 1.0f && vv >= 0.0f && vv < 1.0f)) return 1.0f;
-    int ix = (int)floorf(uu * (float)U.sm_w), iy = (int)floorf(vv * (float)U.sm_h);
-    ix = ix > U.sm_w - 1 ? U.sm_w - 1 : ix;
-    iy = iy > U.sm_h - 1 ? U.sm_h - 1 : iy;
-    const float stored = U.shadow_map[(size_t)iy * (size_t)U.sm_w + (size_t)ix];
-    return d > stored * U.sm_onebias ? 0.0f : 1.0f;
 }
 
 template <class S>
@@ -525,7 +528,7 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
     rm_lds_cfloat sv = (rm_lds_cfloat)s_view;
     constexpr int SHAPE = rm_shape<S>::value;
     constexpr bool PLAIN = SHAPE != 0;
-    const bool use_sv = SHAPE == 1 || SHAPE == 3 || (!PLAIN && U.views == nullptr);
+    const bool use_sv = SHAPE == 1 || SHAPE == 3 || SHAPE == 4 || (!PLAIN && U.views == nullptr);
     // this frame's heavy bitmap -> LDS
     if (Q.use_history) {
         const unsigned *bitmap_cur = Q.bitmaps + (size_t)Q.hv_cur * Q.bitmap_words;
@@ -905,13 +908,12 @@ RM_DI void rm_stream_body(const RmParams &U, const S &sc) {
 // RM_LDS_PRIMS of them): every lane then reads the same record, which the LDS serves as a
 // broadcast into VGPRs -- no scalar-load latency per primitive and no SGPR operands in the
 // distance arithmetic.  Larger tables are read from global memory through the scalar cache.
-// (extra16: 16-byte words that follow the table in device memory and are staged behind it: the culling kernel's bounding spheres)
-RM_DI RmLdsPrimPtr rm_stage_table(const RmParams &U, unsigned lds_word_offset, unsigned extra16 = 0) {
+RM_DI RmLdsPrimPtr rm_stage_table(const RmParams &U, unsigned lds_word_offset) {
     extern __shared__ __attribute__((aligned(16))) unsigned s_dyn[];
     unsigned *base = s_dyn + lds_word_offset;
     const uint4 *src = reinterpret_cast<const uint4 *>(U.prim_table);
     uint4 *dst = reinterpret_cast<uint4 *>(base);
-    const unsigned n16 = (unsigned)U.lds_prims * (sizeof(RmPrimDev) / 16) + extra16;
+    const unsigned n16 = (unsigned)U.lds_prims * (sizeof(RmPrimDev) / 16);
     for (unsigned i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
     return (RmLdsPrimPtr)(base);

@@ -43,8 +43,9 @@ hipError_t rm_reduce_stats(const unsigned *partials, unsigned n_blocks, unsigned
 hipError_t rm_launch_queue(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu);
 // the instantiation rm_launch_queue picks for U: 1 = the plain frame (4-slot scene, fragment pass, whole frame, one pose with
 // the view in the arguments, no source image or depth texture, all three output planes), 2 = the same for a batch of poses
-// with their views in device memory, 3 = as 1 but with source image and depth texture (the reference's Blit), 0 = the
-// general kernel
+// with their views in device memory, 3 = as 1 but with source image and depth texture (the reference's Blit), 4 = as 1 with the
+// shadow term looked up in the bound _ShadowMap (U.shadow_mode != 0) instead of marched, 0 = the general kernel (which has no
+// lookup: with U.shadow_mode != 0 only shape 4 may be launched)
 int rm_queue_shape(const RmParams &U);
 int rm_variant_index(const RmParams &U);
 
@@ -57,8 +58,6 @@ bool rm_stream_is_coop(const RmParams &U);
 // the persistent kernel with the march loops on the fast (tolerance, not bit-exact) distance evaluation; 4-slot scenes
 // only; same calling convention as rm_launch_queue
 hipError_t rm_launch_fast(const RmParams &U, unsigned blocks, hipStream_t stream, int *blocks_per_cu);
-// the tolerance kernel for N-primitive smooth-union scenes (per-step culling against bounding spheres); tile-kernel grid
-hipError_t rm_launch_cull_tiles(const RmParams &U, hipStream_t stream);
 
 // exact kernel for table scenes: one block per 8x8 tile, its four waves share the tile's rays and split the table
 // (tables of at least RM_COOP_MIN_PRIMS primitives that are staged whole in LDS; 3 is the smallest table that splits into

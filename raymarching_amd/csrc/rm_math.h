@@ -83,7 +83,8 @@ template <class S> struct rm_is_fast { static constexpr bool value = false; };
 // A scene type can promise a plain launch shape: fragment pass, whole frames, no source image, no depth texture, all three
 // output planes, frame size with exact reciprocals -- either one frame with the view in the kernel arguments (1) or a
 // batch of poses with the views in device memory (2); or one frame as (1) but WITH source image and depth texture, which
-// is what Graphics.Blit(src, dest, mat) of the reference passes (3).  The per-tile code then drops the uniform branches (and the scalar
+// is what Graphics.Blit(src, dest, mat) of the reference passes (3); or one frame as (1) whose shadow term is a lookup in the bound
+// _ShadowMap instead of the soft-shadow march (4).  The per-tile code then drops the uniform branches (and the scalar
 // registers their conditions occupy) that the other launch shapes need.  0 = any shape.
 template <class S> struct rm_shape { static constexpr int value = 0; };
 

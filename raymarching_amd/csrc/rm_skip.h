@@ -68,6 +68,7 @@ struct SceneNSkip {
     int groups;                    // leaves of the chunk / 4, a power of two
     unsigned long long all[2];     // one bit per leaf of the chunk
     unsigned long long mask[2];    // the leaves the next evaluation visits
+    mutable unsigned n_visited = 0, n_possible = 0;    // leaf evaluations this wave executed / a full walk of its chunk would have
 #ifdef RM_SKIP_STATS               // developer build: leaves visited by the slowest wave / by all four, per evaluation
     mutable unsigned st_max = 0, st_sum = 0, st_n = 0, st_par = 0;
     int st_phase = 0;              // 1 primary march, 2 shadow march
@@ -231,6 +232,8 @@ struct SceneNSkip {
         float mine = 0.0f;
         if (cullable) mine = walk(p);
         else if (coop.part.n > 0) mine = coop.part.w(p);
+        n_visited += cullable ? (unsigned)(__builtin_popcountll(mask[0]) + __builtin_popcountll(mask[1])) : (unsigned)coop.part.n;
+        n_possible += (unsigned)coop.part.n;
 #ifdef RM_SKIP_STATS
         if (coop.lane == 0) st_lds[st_par * 4u + coop.wv] = (unsigned)(__builtin_popcountll(mask[0]) + __builtin_popcountll(mask[1]));
         const float r = coop.finish(mine);                 // has the barrier
@@ -310,6 +313,7 @@ RM_DI PixelOut compute_pixel(const RmParams &U, SKIP &sc, const STRICT &strict, 
                 n = rm_normalize(raw);
                 s = strict.full(hp);
             }
+            sc.n_visited += (unsigned)sc.coop.part.n; sc.n_possible += (unsigned)sc.coop.part.n;      // the colour evaluation walks the whole table
         }
         // ---- getshadow (shader:102-123), hit lanes only ----
         const float c0 = contact;

@@ -137,6 +137,12 @@ class Material:
         self._ck(self._lib.rm_get_stats(self._ctx, C.byref(s)))
         return {"n_pixels": s.n_pixels, "n_hit": s.n_hit, "sum_steps_p": s.sum_steps_p, "sum_steps_s": s.sum_steps_s}
 
+    def leaf_stats(self) -> dict:
+        """leaf evaluations executed / possible in the last call of the table kernel with exact culling (rm_get_leaf_stats)"""
+        v, p = C.c_uint64(), C.c_uint64()
+        self._ck(self._lib.rm_get_leaf_stats(self._ctx, C.byref(v), C.byref(p)))
+        return {"visited": int(v.value), "possible": int(p.value)}
+
     def pack_rgb(self, rgba, rgb, stream=None) -> None:
         """device RGBA8 tensor [..., 4] -> device RGB8 tensor [..., 3] (frame transport: the blit's alpha is constant)"""
         n = rgba.numel() // 4

@@ -78,6 +78,7 @@ SYMBOLS = [
     ("rm_expand_frames_device", C.c_int, [_P, _P, C.c_uint32, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     ("rm_update_frames_device", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     ("rm_get_stats", C.c_int, [_P, C.POINTER(RmStats)]),
+    ("rm_get_leaf_stats", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("rm_debug_counter_slots", C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("rm_set_kernel", C.c_int, [_P, C.c_int]),
 ]

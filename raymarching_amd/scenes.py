@@ -47,6 +47,33 @@ def shadow_camera(width: int = 100, height: int = 100) -> Camera:
     return Camera(transform=t, fieldOfView=60.0, aspect=width / height, nearClipPlane=0.3, farClipPlane=1000.0)
 
 
+def light_camera(sw: int, sh: int) -> Camera:
+    """a shadow camera 20 units from the objects towards the light (_WorldSpaceLightPos0), looking back at them: what a
+    ShadowMap component placed at the light would render (Assets/ShadowMap.cs:50-56)"""
+    centre = np.array([-3.0, 0.5, 0.5])
+    L = WORLD_SPACE_LIGHT_POS0[:3].astype(np.float64)
+    pos = centre + 20.0 * L
+    return Camera(transform=Transform(position=pos.astype(F), rotation=quat_look_rotation(centre - pos)), fieldOfView=50.0,
+                  aspect=sw / sh, nearClipPlane=0.3, farClipPlane=1000.0)
+
+
+def light_rectangle() -> Transform:
+    """a ShadowMapDirectional rectangle (Assets/ShadowMapDirectional.cs:25-34): 24 x 14 units, 20 units from the objects
+    towards the light, facing them"""
+    centre = np.array([-3.0, 0.5, 0.5])
+    L = WORLD_SPACE_LIGHT_POS0[:3].astype(np.float64)
+    pos = centre + 20.0 * L
+    return Transform(position=pos.astype(F), rotation=quat_look_rotation(centre - pos), lossyScale=vec3(24, 14, 1))
+
+
+def closeup_camera(centre, width: int, height: int) -> Camera:
+    """a camera 3.4 units from `centre`, looking at it, fov 60: the close-up view of a fractal scene() body around slot 0"""
+    centre = np.asarray(centre, dtype=np.float64)
+    pos = centre + np.array([2.1, 1.3, -2.3])
+    return Camera(transform=Transform(position=pos.astype(F), rotation=quat_look_rotation(centre - pos)),
+                  fieldOfView=60.0, aspect=width / height, nearClipPlane=0.3, farClipPlane=1000.0)
+
+
 def orbit_camera(k: int, n: int = 64, width: int = 7680, height: int = 4320) -> Camera:
     """Pose k of n on a circle of radius 11.5 about (-3, .5, .5) at height 1, looking
     at the centre; fov 80."""

@@ -86,6 +86,7 @@ public static class RmHip
     [DllImport(Lib)] public static extern int rm_shadowmap_directional_bands_device(IntPtr ctx, float[] corners12, float[] forward3, IntPtr dDepth, IntPtr dHit,
                                                                                     int w, int h, int bandRows, int part, int nParts, IntPtr hipStream);
     [DllImport(Lib)] public static extern int rm_get_stats(IntPtr ctx, out Stats stats);
+    [DllImport(Lib)] public static extern int rm_get_leaf_stats(IntPtr ctx, out ulong visited, out ulong possible);
     [DllImport(Lib)] public static extern int rm_debug_counter_slots(IntPtr ctx, [Out] uint[] words, int maxWords, out int wordsPerSlot, out int nSlots);
     [DllImport(Lib)] public static extern int rm_set_kernel(IntPtr ctx, int variant);
 

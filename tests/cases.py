@@ -53,23 +53,7 @@ def synthetic_depth(w: int, h: int) -> np.ndarray:
     return d
 
 
-def light_camera(sw: int, sh: int):
-    """a shadow camera 20 units from the objects towards the light (_WorldSpaceLightPos0), looking back at them"""
-    from raymarching_amd.unity import Camera, quat_look_rotation
-    centre = np.array([-3.0, 0.5, 0.5])
-    L = scenes.WORLD_SPACE_LIGHT_POS0[:3].astype(np.float64)
-    pos = centre + 20.0 * L
-    return Camera(transform=Transform(position=pos.astype(F), rotation=quat_look_rotation(centre - pos)), fieldOfView=50.0,
-                  aspect=sw / sh, nearClipPlane=0.3, farClipPlane=1000.0)
-
-
-def light_rectangle() -> Transform:
-    """the ShadowMapDirectional rectangle: 24 x 14 units, 20 units from the objects towards the light, facing them"""
-    from raymarching_amd.unity import quat_look_rotation
-    centre = np.array([-3.0, 0.5, 0.5])
-    L = scenes.WORLD_SPACE_LIGHT_POS0[:3].astype(np.float64)
-    pos = centre + 20.0 * L
-    return Transform(position=pos.astype(F), rotation=quat_look_rotation(centre - pos), lossyScale=vec3(24, 14, 1))
+light_camera, light_rectangle = scenes.light_camera, scenes.light_rectangle
 
 
 class Case:
@@ -162,11 +146,7 @@ def _fractal(body, closeup, scale=None, rot=None, fscale=None, power=None):
             ts[0].rotation = rot.astype(F)
         cam = None
         if closeup:
-            centre = ts[0].position.astype(np.float64)
-            pos = centre + np.array([2.1, 1.3, -2.3])
-            from raymarching_amd.unity import Camera, quat_look_rotation
-            cam = Camera(transform=Transform(position=pos.astype(F), rotation=quat_look_rotation(centre - pos)),
-                         fieldOfView=60.0, aspect=case.w / case.h, nearClipPlane=0.3, farClipPlane=1000.0)
+            cam = scenes.closeup_camera(ts[0].position, case.w, case.h)
         _base(mat, case.w, case.h, camera=cam, transforms=ts)
         mat.SetFloat("_RmSceneBody", body)
         if fscale is not None:

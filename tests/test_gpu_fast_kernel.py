@@ -56,61 +56,12 @@ def test_fast_kernel_depth_passes(torch_cuda, name):
     assert mask_bad <= 1e-4 * n and depth_bad <= 1e-4 * n
 
 
-@pytest.mark.parametrize("name,slack,fastm", [("prims4_as_table_320x180", None, 0), ("prims4_as_table_320x180", 0.75, 1)])
-def test_culling_kernel_within_the_tolerance_of_the_port(torch_cuda, name, slack, fastm):
-    """table scenes that are plain smooth unions take the culling kernel under rm_set_kernel(ctx, 4): every march step
-    visits only the primitives whose bounding sphere can reach the result; on the reference's own four primitives as a
-    table the frame stays within the port's tolerance"""
-    from raymarching_amd import Material
-    from test_gpu_parity import _render_once
-    case = cases.BY_NAME[name]
-    ref = gpu_run(case, torch_cuda, kernel=KERNELS["tile"])
-    with Material() as mat:
-        mat.set_kernel(FAST)
-        src, sd = case.bind(mat)
-        if slack is not None:
-            mat.SetFloat("_RmCullSlack", slack)
-        mat.SetFloat("_RmCullFastMath", float(fastm))
-        got = _render_once(case, torch_cuda, mat, src, sd, False)
-    res = assert_frame_close(got, ref, name)
-    _report(f"{name} cull slack={slack} fastmath={fastm}", res, case.w * case.h)
-
-
-@pytest.mark.parametrize("name", ["stress256_320x180", "stress13_200x112", "stress256_1920x1080"])
-def test_culling_kernel_on_the_stress_scene(torch_cuda, name):
-    """The 256-primitive stress scene (grazing rays over a bumpy slab, a third of the pixels hit) amplifies last-bit
-    differences of the scene value into different termination steps: no evaluation that is not bit-exact stays inside the
-    port's tolerance there -- strict arithmetic with culling alone misses it by the same margin as the fast arithmetic.
-    What holds, and is checked: the mask but for 0.01 % of the pixels, 99.9 % of the depths within 1e-4 relative, 99 % of
-    the colours within 1/255, and the step counts within 0.01 %.  The measured counts go to the gate report."""
-    from raymarching_amd import Material
-    from test_gpu_parity import _render_once
-    case = cases.BY_NAME[name]
-    ref = gpu_run(case, torch_cuda, kernel=KERNELS["tile"])
-    n = case.w * case.h
-    for slack, fastm in ((None, 0), (1.0, 1)):
-        with Material() as mat:
-            mat.set_kernel(FAST)
-            src, sd = case.bind(mat)
-            if slack is not None:
-                mat.SetFloat("_RmCullSlack", slack)
-            mat.SetFloat("_RmCullFastMath", float(fastm))
-            got = _render_once(case, torch_cuda, mat, src, sd, False)
-        mask_bad = int((got["hit"] != ref["hit"]).sum())
-        same = got["hit"] == ref["hit"]
-        rel = np.abs(got["depth"].astype(np.float64) - ref["depth"]) / np.maximum(np.abs(ref["depth"]), 1e-30)
-        depth_bad = int((rel[same] > 1e-4).sum())
-        col_bad = int((np.abs(got["rgba"].astype(np.int32) - ref["rgba"].astype(np.int32)).max(axis=-1) > 1).sum())
-        _report(f"{name} cull slack={slack} fastmath={fastm}", {"mask_bad": mask_bad, "depth_bad": depth_bad, "col_bad": col_bad}, n)
-        assert mask_bad <= 1e-4 * n + 1 and depth_bad <= 1e-3 * n + 2 and col_bad <= 1e-2 * n + 4
-        assert abs(got["stats"]["sum_steps_p"] - ref["stats"]["sum_steps_p"]) <= 1e-4 * ref["stats"]["sum_steps_p"] + 64
-        assert abs(got["stats"]["sum_steps_s"] - ref["stats"]["sum_steps_s"]) <= 1e-3 * ref["stats"]["sum_steps_s"] + 64
-
-
-@pytest.mark.parametrize("name", ["csg7_480x270", "menger_closeup_320x180", "fx_bounce_320x180", "dom_repeat_xz_320x180"])
+@pytest.mark.parametrize("name", ["csg7_480x270", "menger_closeup_320x180", "fx_bounce_320x180", "dom_repeat_xz_320x180",
+                                  "prims4_as_table_320x180", "stress13_200x112", "stress256_320x180"])
 def test_fast_kernel_falls_back_to_the_exact_kernels_elsewhere(oracle, torch_cuda, name):
-    """table scenes with op bits, fractal bodies, the optional frag lines and the domain operators have no tolerance kernel:
-    asking for it renders them with the exact ones"""
+    """table scenes, fractal bodies, the optional frag lines and the domain operators have no tolerance kernel: asking for
+    it renders them with the exact ones (a per-step culling kernel for tables existed; on the 256-primitive scene it missed
+    the port's tolerance and lost to the exact culling of the shared-tile kernel, so it was removed)"""
     from helpers import assert_frame_equal
     case = cases.BY_NAME[name]
     assert_frame_equal(gpu_run(case, torch_cuda, kernel=FAST), cases.oracle_run(case, oracle), name)

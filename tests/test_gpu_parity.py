@@ -292,6 +292,29 @@ def test_directional_depth_pass_in_bands_reassembles_to_the_full_map(oracle, tor
         assert lib.rm_shadowmap_directional_bands_device(mat.handle, _fp(c), _fp(f), _ptr(out_d), None, w, h, 8, 2, 2, None) == native.RM_E_ARG
 
 
+def test_leaf_statistics_of_the_exact_culling(torch_cuda):
+    """rm_get_leaf_stats: the culled marches execute a part of the leaf evaluations a full table walk would; with the
+    culling off, or after a launch of another kernel, there is nothing to report"""
+    torch = torch_cuda
+    from raymarching_amd import Material, native
+    case = cases.BY_NAME["stress256_320x180"]
+    with Material() as mat:
+        src, sd = case.bind(mat)
+        _render_once(case, torch, mat, src, sd, False)
+        ls = mat.leaf_stats()
+        st = mat.stats()
+        evals = st["sum_steps_p"] + st["sum_steps_s"]
+        assert 0 < ls["visited"] < ls["possible"]
+        # every wave evaluation could have visited its 64 leaves; a tile's four waves make at least one evaluation per
+        # 64 pixel evaluations, and never more than one per pixel evaluation (plus 7 per hit tile)
+        assert ls["possible"] % 64 == 0 and ls["possible"] >= 256 * (evals // 64)
+        assert 0.2 < ls["visited"] / ls["possible"] < 0.9
+        mat.SetFloat("_RmTableSkip", 0.0)
+        _render_once(case, torch, mat, src, sd, False)
+        with pytest.raises(native.RmError):
+            mat.leaf_stats()
+
+
 def test_pose_batch_equals_single_blits(oracle, torch_cuda):
     """rm_blit_poses_device over 5 orbit poses == 5 x (SetMatrix x2 + Blit), and pose 3 == the oracle"""
     torch = torch_cuda
