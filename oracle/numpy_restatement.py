@@ -223,20 +223,20 @@ def c_log(xf):
 
 
 def c_pow(xf, e):
-    """x >= 0 (a length), e a scalar float32"""
-    e = f(e)
+    """x >= 0 (a length), e a float32 scalar or an array like x"""
+    e = np.asarray(e, dtype=f)
     pos = (xf > 0) & np.isfinite(xf)
     with np.errstate(all="ignore"):
-        v = _expd(d(e) * _logd(np.where(pos, xf.astype(d), 1.0))).astype(f)
-    at0 = f(0) if e > 0 else (f(1) if e == 0 else f(np.inf))
-    atinf = f(np.inf) if e > 0 else (f(1) if e == 0 else f(0))
+        v = _expd(e.astype(d) * _logd(np.where(pos, xf.astype(d), 1.0))).astype(f)
+    at0 = np.where(e > 0, f(0), np.where(e == 0, f(1), f(np.inf)))
+    atinf = np.where(e > 0, f(np.inf), np.where(e == 0, f(1), f(0)))
     special = np.where(xf == 0, at0, np.where(np.isposinf(xf), atinf, f(np.nan)))
     return np.where(pos, v, special).astype(f)
 
 
 def _bulb(x, y, z, e, brot):
-    """cginc:194-227 (mandelbulb, brot False) and cginc:229-262 (mandelbrot, brot True)"""
-    e = f(e)
+    """cginc:194-227 (mandelbulb, brot False) and cginc:229-262 (mandelbrot, brot True); e a scalar or one exponent per point"""
+    e_all = np.broadcast_to(np.asarray(e, dtype=f), x.shape)
     px, py, pz = x, y, z
     zx, zy, zz = x.copy(), y.copy(), z.copy()
     dr = np.ones_like(x)
@@ -263,6 +263,7 @@ def _bulb(x, y, z, e, brot):
         idx, ax, ay, az, rr = idx[go], ax[go], ay[go], az[go], rr[go]
         if idx.size == 0:
             break
+        e = e_all[idx]
         with np.errstate(all="ignore"):
             ratio = az / rr
         if brot:
@@ -414,8 +415,15 @@ class Scene:
         self.fpower = props.get("_RmFractalPower", 0.0)
         if not self.fpower > 0:
             self.fpower = 7.0 if self.body == 3 else 2.0
-        self.fms = euler_matrices(props.get("_FractalRotationX", 0.0), props.get("_FractalRotationY", 0.0),
-                                  props.get("_FractalRotationZ", 0.0))
+        import math
+        t = f(np.asarray(props.get("_Time", (0, 0, 0, 0)), dtype=f)[1])
+        angles = [f(props.get("_FractalRotationX", 0.0)), f(props.get("_FractalRotationY", 0.0)), f(props.get("_FractalRotationZ", 0.0))]
+        if props.get("_RmAnimateFractal", 0.0):                 # cginc:346-348
+            angles = [f(math.sin(float(t))) * f(.5), f(math.sin(float(t * f(1.414)))) * f(.5), f(math.sin(float(t * f(1.618)))) * f(.5)]
+        self.fms = euler_matrices(*angles)
+        # cginc:349: rotate(p, float3(0, 0, _Time.y)) and rotate(p, float3(_Time.y*.25, _Time.y*1.4*.25, _Time.y*1.6*.25))
+        self.ms_time = euler_matrices(f(0), f(0), t)
+        self.ms_sponge = euler_matrices(t * f(.25), t * f(1.4) * f(.25), t * f(1.6) * f(.25))
         self.dom_op = int(props.get("_RmDomainOp", 0))
         self.dom_period = [f(v) for v in list(props.get("_RmDomainPeriod", (0, 0, 0, 0)))[:3]]
         self.dom_size = props.get("_RmDomainSize", 1.0)
@@ -467,6 +475,9 @@ class Scene:
         operand carries the SMAX bit, smin (cginc:110-113) otherwise."""
         if self.dom_op:
             x, y, z = self.domain(x, y, z)
+        if self.body == 6:                        # cginc:349 on the world-space p, no wrapper
+            _, mw = menger(*rotate_euler(x, y, z, self.ms_sponge), self.fms)
+            return _bulb(*rotate_euler(x, y, z, self.ms_time), mw + f(1.1), False)
         if self.body:
             p0 = self.slot0
             lx, ly, lz = rotate_q(x - p0["pos"][0], y - p0["pos"][1], z - p0["pos"][2], p0["quat"])

@@ -116,6 +116,24 @@ static inline f4 smax4(f4 a, f4 b, float k) {
     return r;
 }
 
+/* ---- helpers the reference defines and no live code calls (restated so that nothing of the .cginc is left without a
+ * checked restatement) ---------------------------------------------------------------------------------------------
+ * cginc:105-108  smin(float a, float b, k): the scalar overload, same arithmetic as the .w lane of the float4 one */
+static inline float smin1(float a, float b, float k) {
+    float h = clamp1(0.5f + 0.5f * (b - a) / k, 0.0f, 1.0f);
+    return lerp1(b, a, h) - k * h * (1.0f - h);
+}
+/* cginc:115-118  smax(float a, float b, k).  Unlike the float4 overload (cginc:120-123, "-lerp(-b.w, -a.w, h)") the scalar
+ * one returns lerp(-b, -a, h) WITHOUT the outer negation: for a >= b + k it returns -a, not a.  Restated as written. */
+static inline float smax1(float a, float b, float k) {
+    float h = clamp1(0.5f + 0.5f * (a - b) / k, 0.0f, 1.0f);
+    return lerp1(-b, -a, h) - k * h * (1.0f - h);
+}
+/* cginc:68-74  sq */
+static inline float sq1(float x) { return x * x; }
+/* cginc:151-154  luminance: the Rec. 601 weights of the live line */
+static inline float luminance3(f3 c) { return c.x * 0.2990f + c.y * 0.5870f + c.z * 0.1140f; }
+
 /* primitive wrapper: p_i = rotate(p - pos, q);  o = prim(p_i / scale) * min(scale)
  * (cginc:336-354) */
 static inline float prim_dist(const rmo_prim *pr, f3 p) {
@@ -467,10 +485,19 @@ typedef struct {
     float pow3;            /* pow(3.0, -12)            (cginc:312) */
     float pows[16];        /* pow(_FractalScale, -i)   (cginc:292) */
     float fpower;          /* e of mandelbulb (default 7, cginc:194) / mandelbrot (default 2, cginc:229) */
+    euler_t rot_time;      /* cos/sin of float3(0, 0, _Time.y)                                  (cginc:349) */
+    euler_t rot_menger;    /* cos/sin of float3(_Time.y*.25, _Time.y*1.4*.25, _Time.y*1.6*.25)  (cginc:349) */
 } scene_ctx;
+
+/* cginc:349, the body scene() returns when the commented line is live: the world-space p, no wrapper */
+static inline f4 scene_composite(const scene_ctx *c, f3 p) {
+    float e = menger(rotate_euler(p, &c->rot_menger), &c->frot, c->pow3).w + 1.1f;
+    return mandelbulb(rotate_euler(p, &c->rot_time), e);
+}
 
 /* fractal scene(): the per-primitive wrapper of cginc:336-354 with slot 0, around a fractal body */
 static inline f4 scene_fractal(const scene_ctx *c, f3 p) {
+    if (c->body == RMO_BODY_COMPOSITE) return scene_composite(c, p);
     const rmo_prim *pr = &c->legacy[0];
     f3 pos = v3(pr->pos[0], pr->pos[1], pr->pos[2]);
     f4 q = {pr->quat[0], pr->quat[1], pr->quat[2], pr->quat[3]};
@@ -703,6 +730,17 @@ static void scene_ctx_init(scene_ctx *c, const rmo_uniforms *u) {
     else { c->prims = c->legacy; c->n = 4; }
     c->body = u->scene_body;
     c->frot = euler_of(u->fractal_rotation);
+    {
+        const float t = u->time[1];
+        if (u->animate_fractal) {                                       /* cginc:346-348 */
+            float a[3] = {(float)sin((double)t) * .5f, (float)sin((double)(t * 1.414f)) * .5f, (float)sin((double)(t * 1.618f)) * .5f};
+            c->frot = euler_of(a);
+        }
+        float at[3] = {0.0f, 0.0f, t};
+        float am[3] = {t * .25f, t * 1.4f * .25f, t * 1.6f * .25f};
+        c->rot_time = euler_of(at);
+        c->rot_menger = euler_of(am);
+    }
     c->pow3 = (float)pow(3.0, -12.0);
     c->fpower = u->fractal_power > 0.0f ? u->fractal_power : (u->scene_body == RMO_BODY_MANDELBULB ? 7.0f : 2.0f);
     for (int i = 0; i < 16; i++) c->pows[i] = (float)pow((double)u->fractal_scale, -(double)i);
@@ -1018,6 +1056,20 @@ void rmo_smin4(const float a[4], const float b[4], float k, float out[4]) {
     f4 aa = {a[0], a[1], a[2], a[3]}, bb = {b[0], b[1], b[2], b[3]};
     f4 r = smin4(aa, bb, k);
     out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+float rmo_smin1(float a, float b, float k) { return smin1(a, b, k); }
+float rmo_smax1(float a, float b, float k) { return smax1(a, b, k); }
+float rmo_sq(float x) { return sq1(x); }
+void rmo_sq3(const float x[3], float out[3]) { out[0] = sq1(x[0]); out[1] = sq1(x[1]); out[2] = sq1(x[2]); }
+float rmo_luminance(const float c[3]) { return luminance3(v3(c[0], c[1], c[2])); }
+/* shader:80-82  getnormal(p, s=0) = normalize(getnormalraw(p, s)); raw receives the un-normalised differences */
+void rmo_getnormal(const rmo_uniforms *u, const float p[3], float out[3], float raw[3]) {
+    scene_ctx c;
+    scene_ctx_init(&c, u);
+    f3 r = getnormalraw(&c, v3(p[0], p[1], p[2]));
+    f3 n = normalize3(r);
+    out[0] = n.x; out[1] = n.y; out[2] = n.z;
+    if (raw) { raw[0] = r.x; raw[1] = r.y; raw[2] = r.z; }
 }
 void rmo_scene(const rmo_uniforms *u, const float p[3], float out[4]) {
     scene_ctx c;

@@ -112,6 +112,12 @@ typedef struct {
     float shadow_corners[12];    /* directional: TL,TR,BR,BL as ShadowMapDirectional.cs:11-16 orders them */
     float shadow_forward[3];
     float shadow_bias;
+    /* _Time, Unity's built-in (t/20, t, 2t, 3t); only .y is read, by the composite body and the animated angles below */
+    float time[4];
+    /* 1: the three lines cginc:346-348 run: _FractalRotationX/Y/Z = sin(_Time.y)*.5, sin(_Time.y*1.414)*.5,
+     * sin(_Time.y*1.618)*.5 replace the material's values (uniform-only: evaluated once per frame, sin as the double libm value
+     * rounded to float like every cos/sin of a uniform angle here) */
+    int32_t animate_fractal;
 } rmo_uniforms;
 
 /* scene() bodies.  PRIMS is the reference's active code (cginc:336-363).  The fractal bodies are
@@ -121,7 +127,12 @@ typedef struct {
 enum { RMO_BODY_PRIMS = 0, RMO_BODY_MENGER = 1, RMO_BODY_SIERPINSKI = 2, RMO_BODY_MANDELBULB = 3, RMO_BODY_MANDELBROT = 4,
        /* terrain(float2) (cginc:315-330) returns a height that no code of the reference turns into a distance; this
         * build's definition of the body: t = terrain(p.xz); float4(t.rgb, p.y - t.w) */
-       RMO_BODY_TERRAIN = 5 };
+       RMO_BODY_TERRAIN = 5,
+       /* the line the reference keeps commented out at cginc:349, literally -- on the world-space p, without the slot-0 wrapper:
+        *   mandelbulb(rotate(p, float3(0, 0, _Time.y)),
+        *              menger(rotate(p, float3(_Time.y*.25, _Time.y*1.4*.25, _Time.y*1.6*.25))).w + 1.1)
+        * i.e. a mandelbulb whose exponent varies from point to point with the distance to a (differently rotated) menger sponge */
+       RMO_BODY_COMPOSITE = 6 };
 
 typedef struct {
     uint64_t n_pixels;
@@ -181,6 +192,12 @@ void  rmo_mandelbrot(const float p[3], float e, float out[4]);
 void  rmo_menger(const rmo_uniforms *u, const float p[3], float out[4]);
 void  rmo_sierpinski(const rmo_uniforms *u, const float p[3], float out[4]);
 void  rmo_smax4(const float a[4], const float b[4], float k, float out[4]);
+float rmo_smin1(float a, float b, float k);                 /* cginc:105-108 */
+float rmo_smax1(float a, float b, float k);                 /* cginc:115-118 */
+float rmo_sq(float x);                                      /* cginc:68-70 */
+void  rmo_sq3(const float x[3], float out[3]);              /* cginc:72-74 */
+float rmo_luminance(const float c[3]);                      /* cginc:151-154 */
+void  rmo_getnormal(const rmo_uniforms *u, const float p[3], float out[3], float raw[3]);   /* shader:80-82 */
 void  rmo_scene(const rmo_uniforms *u, const float p[3], float out[4]);
 void  rmo_pixel_ray(const rmo_uniforms *u, int x, int y, int w, int h, float rd[3]);
 int   rmo_vert_corner_index(float uvx, float uvy);

@@ -37,7 +37,7 @@ class RmoUniforms(C.Structure):
                 ("domain_op", C.c_int32), ("domain_period", C.c_float * 3), ("domain_size", C.c_float),
                 ("shadow_mode", C.c_int32), ("shadow_map", C.POINTER(C.c_float)), ("shadow_w", C.c_int32), ("shadow_h", C.c_int32),
                 ("shadow_vp", C.c_float * 16), ("shadow_corners", C.c_float * 12), ("shadow_forward", C.c_float * 3),
-                ("shadow_bias", C.c_float)]
+                ("shadow_bias", C.c_float), ("time", C.c_float * 4), ("animate_fractal", C.c_int32)]
 
 
 class RmoStats(C.Structure):
@@ -117,6 +117,17 @@ def lib() -> C.CDLL:
             fn.argtypes = [C.POINTER(RmoUniforms), FP, FP]
         l.rmo_smax4.restype = None
         l.rmo_smax4.argtypes = [FP, FP, C.c_float, FP]
+        for fn in (l.rmo_smin1, l.rmo_smax1):
+            fn.restype = C.c_float
+            fn.argtypes = [C.c_float, C.c_float, C.c_float]
+        l.rmo_sq.restype = C.c_float
+        l.rmo_sq.argtypes = [C.c_float]
+        l.rmo_sq3.restype = None
+        l.rmo_sq3.argtypes = [FP, FP]
+        l.rmo_luminance.restype = C.c_float
+        l.rmo_luminance.argtypes = [FP]
+        l.rmo_getnormal.restype = None
+        l.rmo_getnormal.argtypes = [UP, FP, FP, FP]
         l.rmo_scene.restype = None
         l.rmo_scene.argtypes = [UP, FP, FP]
         l.rmo_pixel_ray.restype = None
@@ -194,6 +205,8 @@ class Uniforms:
         u.domain_size = props.get("_RmDomainSize", 1.0)
         u.fractal_rotation[:] = [props.get("_FractalRotationX", 0.0), props.get("_FractalRotationY", 0.0),
                                  props.get("_FractalRotationZ", 0.0)]
+        u.time[:] = f32(props.get("_Time", np.zeros(4))).tolist()
+        u.animate_fractal = int(props.get("_RmAnimateFractal", 0) != 0)
         u.shadow_mode = int(props.get("_RmShadowMode", 0))
         u.shadow_bias = props.get("_RmShadowBias", 0.01)
         u.shadow_vp[:] = f32(props.get("_ShadowMapVPMatrix", np.eye(4))).tolist()
@@ -215,10 +228,10 @@ class Uniforms:
 
 PROP_MATRICES = ("_FrustrumCorners", "_CameraInvViewMatrix", "_Positions", "_Rotations", "_Scales", "_ShadowMapVPMatrix",
                  "_RmShadowMapCorners")
-PROP_VECTORS = ("_WorldSpaceCameraPos", "_WorldSpaceLightPos0", "_ProjectionParams", "_BackgroundColor", "_RmDomainPeriod", "_RmShadowMapForward", "_LightPosition")
+PROP_VECTORS = ("_WorldSpaceCameraPos", "_WorldSpaceLightPos0", "_ProjectionParams", "_BackgroundColor", "_RmDomainPeriod", "_RmShadowMapForward", "_LightPosition", "_Time")
 PROP_FLOATS = ("_MaxSteps", "_MaxDist", "_StepFactor", "_ContactThreshold", "_NormalSampleScale",
                "_FractalScale", "_FractalRotationX", "_FractalRotationY", "_FractalRotationZ", "_RmSceneBody", "_RmFractalPower",
-               "_RmStepHeat", "_RmDebugView", "_RmVolumetricLight", "_RmBounce", "_RmDomainOp", "_RmDomainSize", "_RmShadowMode", "_RmShadowBias", "_RmLightModel", "_RmScatter", "_RefractiveIndex")
+               "_RmStepHeat", "_RmDebugView", "_RmVolumetricLight", "_RmBounce", "_RmDomainOp", "_RmDomainSize", "_RmShadowMode", "_RmShadowBias", "_RmLightModel", "_RmScatter", "_RefractiveIndex", "_RmAnimateFractal")
 
 
 def props_from_material(mat) -> dict:

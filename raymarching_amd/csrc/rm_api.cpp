@@ -41,6 +41,9 @@ const char *const kDeclared[] = {
     "_WorldSpaceCameraPos", "_WorldSpaceLightPos0", "_ProjectionParams",
     // stands in for _MainTex when no source image is passed
     "_BackgroundColor",
+    // Unity's built-in time vector (t/20, t, 2t, 3t), read by the commented lines cginc:346-349; explicit here.
+    // _RmAnimateFractal 1 = the three lines cginc:346-348 (the fold angles follow sin(_Time.y))
+    "_Time", "_RmAnimateFractal",
     // which scene() body runs: 0 primitives (cginc:336-363), 1 menger (:295-313), 2 sierpinski (:264-293)
     "_RmSceneBody",
     // exponent of the mandelbulb / mandelbrot bodies; 0 = the functions' defaults 7 / 2 (cginc:194,229)
@@ -204,6 +207,8 @@ void load_defaults(rm_ctx *c) {
     c->floats["_FractalRotationZ"] = 0.14f;
     c->floats["_FractalScale"] = 2.0f;
     c->floats["_RmSceneBody"] = 0.0f;
+    c->floats["_RmAnimateFractal"] = 0.0f;
+    c->vectors["_Time"] = {0, 0, 0, 0};
     c->floats["_RmFractalPower"] = 0.0f;
     c->floats["_RmStepHeat"] = 0.0f;
     c->floats["_RmDebugView"] = 0.0f;
@@ -487,8 +492,9 @@ int build_params(rm_ctx *c, RmParams *U, hipStream_t stream) {
     }
     const int body = (int)getf(c, "_RmSceneBody", 0.0f);
     if (body != RM_BODY_PRIMS) {
-        if (body < RM_BODY_MENGER || body > RM_BODY_TERRAIN)
-            return fail(c, RM_E_ARG, "_RmSceneBody must be 0 (primitives), 1 (menger), 2 (sierpinski), 3 (mandelbulb), 4 (mandelbrot) or 5 (terrain)");
+        if (body < RM_BODY_MENGER || body > RM_BODY_COMPOSITE)
+            return fail(c, RM_E_ARG, "_RmSceneBody must be 0 (primitives), 1 (menger), 2 (sierpinski), 3 (mandelbulb), 4 (mandelbrot), "
+                                     "5 (terrain) or 6 (the composite of cginc:349)");
         // the wrapper transform is slot 0 of the matrices, whatever table is set
         rm_primitive lp[4];
         legacy_prims(c, lp);
@@ -501,11 +507,22 @@ int build_params(rm_ctx *c, RmParams *U, hipStream_t stream) {
         U->f_scale = scale;
         U->f_scale_m1 = scale - 1.0f;
         const char *names[3] = {"_FractalRotationX", "_FractalRotationY", "_FractalRotationZ"};
-        for (int i = 0; i < 3; i++) {
-            const double a = (double)getf(c, names[i], 0.0f);
-            U->f_rot[2 * i] = (float)std::cos(a);
-            U->f_rot[2 * i + 1] = (float)std::sin(a);
+        const float t = getv(c, "_Time")[1];
+        float ang[3];
+        for (int i = 0; i < 3; i++) ang[i] = getf(c, names[i], 0.0f);
+        if (getf(c, "_RmAnimateFractal", 0.0f) != 0.0f) {               // cginc:346-348; uniform-only, so taken once per frame
+            ang[0] = (float)std::sin((double)t) * .5f;
+            ang[1] = (float)std::sin((double)(t * 1.414f)) * .5f;
+            ang[2] = (float)std::sin((double)(t * 1.618f)) * .5f;
         }
+        auto cos_sin = [](const float a[3], float out[6]) {
+            for (int i = 0; i < 3; i++) { out[2 * i] = (float)std::cos((double)a[i]); out[2 * i + 1] = (float)std::sin((double)a[i]); }
+        };
+        cos_sin(ang, U->f_rot);
+        const float a_time[3] = {0.0f, 0.0f, t};                       // cginc:349
+        const float a_sponge[3] = {t * .25f, t * 1.4f * .25f, t * 1.6f * .25f};
+        cos_sin(a_time, U->f_rot_time);
+        cos_sin(a_sponge, U->f_rot_sponge);
         const float power = getf(c, "_RmFractalPower", 0.0f);
         U->f_power = power > 0.0f ? power : (body == RM_BODY_MANDELBULB ? 7.0f : 2.0f);
         U->f_pow3 = (float)std::pow(3.0, -12.0);

@@ -150,6 +150,8 @@ struct RmParams {
     float    f_pow3;           // pow(3.0, -12)          (cginc:312)
     float    f_pows[16];       // pow(_FractalScale, -i) (cginc:292)
     float    f_power;          // e of mandelbulb (cginc:194) / mandelbrot (cginc:229)
+    float    f_rot_time[6];    // composite body: cos,sin of float3(0, 0, _Time.y)                                 (cginc:349)
+    float    f_rot_sponge[6];  // composite body: cos,sin of float3(_Time.y*.25, _Time.y*1.4*.25, _Time.y*1.6*.25) (cginc:349)
     // lines of frag the reference keeps commented out (0 = the shader as it stands); tile kernels only
     uint32_t fx_flags;         // RM_FX_*
     int32_t  light_model;      // 0 dot(normal, _WorldSpaceLightPos0)*.5+.5 (shader:199), 1 getbrightness (shader:92-100), 2 getbrightnesshard (:84-90)
@@ -176,4 +178,5 @@ enum : int32_t { RM_DOM_NONE = 0, RM_DOM_REPEAT = 1, RM_DOM_BOXFOLD = 2, RM_DOM_
 
 enum : uint32_t { RM_FX_STEP_HEAT = 1, RM_FX_VOLUMETRIC = 2, RM_FX_BOUNCE = 4, RM_FX_SCATTER = 8, RM_FX_REFRACT2 = 16 };
 
-enum : int32_t { RM_BODY_PRIMS = 0, RM_BODY_MENGER = 1, RM_BODY_SIERPINSKI = 2, RM_BODY_MANDELBULB = 3, RM_BODY_MANDELBROT = 4, RM_BODY_TERRAIN = 5 };
+enum : int32_t { RM_BODY_PRIMS = 0, RM_BODY_MENGER = 1, RM_BODY_SIERPINSKI = 2, RM_BODY_MANDELBULB = 3, RM_BODY_MANDELBROT = 4, RM_BODY_TERRAIN = 5,
+                 RM_BODY_COMPOSITE = 6 };   // the commented line cginc:349: a mandelbulb whose exponent is a menger distance + 1.1

@@ -533,13 +533,15 @@ RM_DI float rm_c_pow_ln(float xf, double lnx, float ef) {
 struct SceneF {
     const RmParams &U;
     PrimV P0;
-    EulerV E;
+    EulerV E, Et, Es;      // _FractalRotationX/Y/Z; composite body: the bulb's and the sponge's rotation of p (cginc:349)
     float three, two, scale, scale_m1;
     bool rot, unit, rcp;
     RM_DI explicit SceneF(const RmParams &u) : U(u) {
         P0 = rm_prim_to_vgpr<true, RM_SCL_RCP>(u.prims4[0]);
         E.cx = rm_vgpr(u.f_rot[0]); E.sx = rm_vgpr(u.f_rot[1]); E.cy = rm_vgpr(u.f_rot[2]);
         E.sy = rm_vgpr(u.f_rot[3]); E.cz = rm_vgpr(u.f_rot[4]); E.sz = rm_vgpr(u.f_rot[5]);
+        Et.cx = u.f_rot_time[0]; Et.sx = u.f_rot_time[1]; Et.cy = u.f_rot_time[2]; Et.sy = u.f_rot_time[3]; Et.cz = u.f_rot_time[4]; Et.sz = u.f_rot_time[5];
+        Es.cx = u.f_rot_sponge[0]; Es.sx = u.f_rot_sponge[1]; Es.cy = u.f_rot_sponge[2]; Es.sy = u.f_rot_sponge[3]; Es.cz = u.f_rot_sponge[4]; Es.sz = u.f_rot_sponge[5];
         three = rm_vgpr(3.0f); two = rm_vgpr(2.0f);
         scale = rm_vgpr(u.f_scale); scale_m1 = rm_vgpr(u.f_scale_m1);
         rot = !(u.scene_flags & RM_SF_IDENT_ROT);
@@ -605,8 +607,8 @@ struct SceneF {
         return r;
     }
     // cginc:194-227 (BROT false) and cginc:229-262 (BROT true); iters = 12, bailout = 10
-    template <bool TRAPS, bool BROT> RM_DI V4 bulb(V3 p) const {
-        const float e = U.f_power, em1 = e - 1.0f;
+    template <bool TRAPS, bool BROT> RM_DI V4 bulb(V3 p, float e) const {
+        const float em1 = e - 1.0f;
         V3 z = p;
         float dr = 1.0f, r = 0.0f;
         float t0 = 100.0f, t1 = 100.0f, t2 = 100.0f;             // bailout^2
@@ -681,14 +683,19 @@ struct SceneF {
         return o;
     }
     template <bool TRAPS> RM_DI V4 eval(V3 p) const {
+        if (U.body == RM_BODY_COMPOSITE) {
+            // cginc:349 on the world-space p (no wrapper): the exponent of the bulb differs from point to point
+            const float e = menger<false>(rm_rotate_euler(Es, p)).w + 1.1f;
+            return bulb<TRAPS, false>(rm_rotate_euler(Et, p), e);
+        }
         const V3 l = local(p);
         V4 o;
         switch (U.body) {                                        // wave-uniform
         case RM_BODY_MENGER:     o = menger<TRAPS>(l); break;
         case RM_BODY_SIERPINSKI: o = sierpinski<TRAPS>(l); break;
-        case RM_BODY_MANDELBULB: o = bulb<TRAPS, false>(l); break;
+        case RM_BODY_MANDELBULB: o = bulb<TRAPS, false>(l, U.f_power); break;
         case RM_BODY_TERRAIN:    o = terrain(l); break;
-        default:                 o = bulb<TRAPS, true>(l); break;
+        default:                 o = bulb<TRAPS, true>(l, U.f_power); break;
         }
         if (!unit) o.w = o.w * P0.ms;
         return o;

@@ -156,6 +156,21 @@ def _fractal(body, closeup, scale=None, rot=None, fscale=None, power=None):
     return f
 
 
+def _composite(t, animate=False, floats=None, near=1.0):
+    """_RmSceneBody 6, the line the reference keeps commented out at cginc:349, at _Time.y = t: a camera 3.4 units from the
+    origin, where the bulb sits (the body reads the world-space p, no wrapper)"""
+    def f(case, mat):
+        cam = scenes.closeup_camera((0.0, 0.0, 0.0), case.w, case.h)
+        cam.transform.position = (cam.transform.position.astype(np.float64) * near).astype(F)      # same direction, nearer
+        _base(mat, case.w, case.h, camera=cam)
+        mat.SetFloat("_RmSceneBody", 6.0)
+        mat.SetVector("_Time", (t / 20.0, t, 2.0 * t, 3.0 * t))
+        mat.SetFloat("_RmAnimateFractal", 1.0 if animate else 0.0)
+        for k, v in (floats or {}).items():
+            mat.SetFloat(k, v)
+    return f
+
+
 def _terrain(scale=1e-4, y0=-3.0, rot=None, floats=None):
     """the terrain body (cginc:315-330 as a height field) under the default camera: slot 0 scaled so that the 30000-unit
     heights and the 1.2e-5 noise frequency of the reference's formula land in the scene's range"""
@@ -331,6 +346,12 @@ CASES = [
     Case("shadowmap_lookup_persp_stress13_lowres_160x90", 160, 90, shadow=("persp", 64, 48), setup=_stress,
          prims=scenes.stress_primitives(13, seed=0x5EED000D)),
     # terrain / noise / rand (cginc:125-149, 315-330) as a scene() body
+    Case("composite_t0_200x112", 200, 112, setup=_composite(0.0)),
+    Case("composite_t0p8_240x135", 240, 135, setup=_composite(0.8)),
+    Case("composite_near_t1p7_200x112", 200, 112, setup=_composite(1.7, near=0.42)),
+    Case("composite_animated_t2p3_bounce_160x90", 160, 90, setup=_composite(2.3, True, {"_RmBounce": 1.0, "_RmStepHeat": 1.0})),
+    Case("menger_animated_t1p1_200x112", 200, 112, setup=lambda c, m: (_fractal(1, True)(c, m), m.SetVector("_Time", (0.055, 1.1, 2.2, 3.3)),
+                                                                       m.SetFloat("_RmAnimateFractal", 1.0))),
     Case("terrain_320x180", 320, 180, setup=_terrain()),
     Case("terrain_rotated_nonuniform_200x112", 200, 112, setup=_terrain(scale=2e-4, y0=-4.0, rot=quat_angle_axis(12.0, (1, 0, 0.3)),
                                                                         floats={"_StepFactor": 0.4})),

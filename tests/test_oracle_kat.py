@@ -360,3 +360,98 @@ def test_light_helpers_closed_forms(oracle):               # shader:84-100, 129-
     assert out.tolist() == pytest.approx([0.6, -0.8, 0.0], abs=1e-7)
     l.rmo_refract2(p3(0.6, -0.8, 0), p3(0, 1, 0), 1.5, fp(out))          # eta' = .5, cosi = -.8: i*.5 - n*(.8 - .4)
     assert out.tolist() == pytest.approx([0.3, -0.8, 0.0], abs=1e-7)
+
+
+def test_scalar_smin_and_smax(oracle):          # cginc:105-108, 115-118
+    """the scalar overloads nothing calls: smin is the .w lane of the float4 one; smax as WRITTEN returns lerp(-b, -a, h)
+    without the outer negation the float4 overload has, i.e. minus the larger operand once they are k apart"""
+    l = oracle.lib()
+    assert l.rmo_smin1(0.0, 1.0, 0.5) == 0.0 and l.rmo_smin1(1.0, 0.0, 0.5) == 0.0
+    assert l.rmo_smin1(0.0, 0.0, 0.5) == -0.125 and l.rmo_smin1(0.25, 0.25, 0.5) == 0.125
+    out = f32([0, 0, 0, 0])
+    rng = np.random.default_rng(5)
+    for a, b in rng.uniform(-2, 2, (200, 2)).astype(np.float32):
+        l.rmo_smin4(fp(f32([1, 0, 0, a])), fp(f32([0, 1, 0, b])), 0.5, fp(out))
+        assert l.rmo_smin1(float(a), float(b), 0.5) == float(out[3])
+    assert l.rmo_smax1(1.0, 0.0, 0.5) == -1.0          # h = 1: lerp(-b, -a, 1) = -a
+    assert l.rmo_smax1(0.0, 1.0, 0.5) == -1.0          # h = 0: -b
+    assert l.rmo_smax1(0.0, 0.0, 0.5) == -0.125
+    for a, b in rng.uniform(-2, 2, (200, 2)).astype(np.float32):
+        l.rmo_smax4(fp(f32([1, 0, 0, a])), fp(f32([0, 1, 0, b])), 0.5, fp(out))
+        h = np.float32(min(max(np.float32(0.5) + np.float32(0.5) * (a - b) / np.float32(0.5), 0), 1))
+        blend = np.float32(0.5) * h * (np.float32(1) - h)
+        # float4: -lerp(-b,-a,h) - k*h*(1-h); scalar: lerp(-b,-a,h) - k*h*(1-h): their sum is -2*k*h*(1-h)
+        np.testing.assert_allclose(l.rmo_smax1(float(a), float(b), 0.5) + float(out[3]), -2.0 * float(blend), atol=1e-6)
+
+
+def test_sq_and_luminance(oracle):              # cginc:68-74, 151-154
+    l = oracle.lib()
+    assert l.rmo_sq(3.0) == 9.0 and l.rmo_sq(-0.5) == 0.25
+    out = f32([0, 0, 0])
+    l.rmo_sq3(p3(1.5, -2.0, 0.0), fp(out))
+    assert out.tolist() == [2.25, 4.0, 0.0]
+    assert l.rmo_luminance(p3(1, 0, 0)) == float(np.float32(0.2990))
+    assert l.rmo_luminance(p3(0, 1, 0)) == float(np.float32(0.5870))
+    assert l.rmo_luminance(p3(0, 0, 1)) == float(np.float32(0.1140))
+    np.testing.assert_allclose(l.rmo_luminance(p3(1, 1, 1)), 1.0, rtol=2e-7)      # the Rec. 601 weights sum to 1
+
+
+def test_getnormal_is_the_normalised_raw_normal(oracle, default_setup):          # shader:80-82
+    """getnormal(p) = normalize(getnormalraw(p)): on the sphere of the default scene (centre (-0.584, 0.049, 0.602), radius .5)
+    the normal at a surface point is the radial direction, to the accuracy the 5e-5 differences allow in binary32"""
+    _, _, props = default_setup(16, 9)
+    l = oracle.lib()
+    uni = oracle.Uniforms(props)
+    c = np.array([-0.584, 0.049, 0.602])
+    d = np.array([0.0, 0.0, -1.0])                                              # the side facing the camera, away from the box
+    n, raw = f32([0, 0, 0]), f32([0, 0, 0])
+    l.rmo_getnormal(uni.ref, fp(f32(c + 0.5 * d)), fp(n), fp(raw))
+    np.testing.assert_allclose(np.linalg.norm(n), 1.0, rtol=1e-6)
+    assert float(np.dot(n, d)) > 0.99
+    # raw is 2e times the gradient (not divided, shader:63-67): |raw| ~ 1e-4
+    assert 0.5e-4 < float(np.linalg.norm(raw)) < 2e-4
+    np.testing.assert_allclose(n, raw / np.float32(np.sqrt(np.float32(np.dot(raw, raw)))), rtol=1e-6)
+
+
+def test_composite_body_of_the_commented_line(oracle, default_setup):            # cginc:346-349
+    """_RmSceneBody 6 = mandelbulb(rotate(p, (0,0,T)), menger(rotate(p, (T/4, 1.4T/4, 1.6T/4))).w + 1.1) on the world-space p.
+    At T = 0 both rotations are the identity, so the value is mandelbulb(p, menger(p).w + 1.1) of the probes below."""
+    _, _, props = default_setup(16, 9)
+    l = oracle.lib()
+    out, m, b = f32([0, 0, 0, 0]), f32([0, 0, 0, 0]), f32([0, 0, 0, 0])
+    props = dict(props, _RmSceneBody=6.0, _Time=f32([0, 0, 0, 0]))
+    uni = oracle.Uniforms(props)
+    for p in ((0.3, -0.2, 0.9), (1.4, 0.1, -0.3), (0.05, -0.02, 2.5)):
+        l.rmo_scene(uni.ref, p3(*p), fp(out))
+        l.rmo_menger(uni.ref, p3(*p), fp(m))
+        l.rmo_mandelbulb(p3(*p), float(np.float32(m[3]) + np.float32(1.1)), fp(b))
+        assert out.tolist() == b.tolist(), p
+    # T != 0: the bulb's argument is p turned about z by T (cginc:51-60 with a = (0, 0, T)); the sponge's by the three angles
+    T = np.float32(0.8)
+    uni_t = oracle.Uniforms(dict(props, _Time=f32([T / 20, T, 2 * T, 3 * T])))
+    p = np.array([0.3, -0.2, 0.9], dtype=np.float32)
+    l.rmo_scene(uni_t.ref, fp(p), fp(out))
+    cz, sz = np.float32(math.cos(float(T))), np.float32(math.sin(float(T)))
+    pz = f32([cz * p[0] - sz * p[1], sz * p[0] + cz * p[1], p[2]])
+    ax, ay, az = T * np.float32(.25), T * np.float32(1.4) * np.float32(.25), T * np.float32(1.6) * np.float32(.25)
+    uni_m = oracle.Uniforms(props)                                               # menger reads _FractalRotationX/Y/Z, unchanged by T
+
+    def rot(v, a):
+        cx, sx, cy, sy, cz_, sz_ = (np.float32(f(float(t))) for t in a for f in (math.cos, math.sin))
+        a1 = f32([v[0], cx * v[1] - sx * v[2], sx * v[1] + cx * v[2]])
+        b1 = f32([cy * a1[0] + sy * a1[2], a1[1], -sy * a1[0] + cy * a1[2]])
+        return f32([cz_ * b1[0] - sz_ * b1[1], sz_ * b1[0] + cz_ * b1[1], b1[2]])
+    l.rmo_menger(uni_m.ref, fp(rot(p, (ax, ay, az))), fp(m))
+    l.rmo_mandelbulb(fp(pz), float(np.float32(m[3]) + np.float32(1.1)), fp(b))
+    np.testing.assert_allclose(out, b, rtol=2e-6, atol=1e-7)
+    # _RmAnimateFractal: the sponge's own fold angles become sin(T)*.5, sin(1.414 T)*.5, sin(1.618 T)*.5 (cginc:346-348)
+    uni_a = oracle.Uniforms(dict(props, _Time=f32([T / 20, T, 2 * T, 3 * T]), _RmAnimateFractal=1.0))
+    anim = dict(props, _FractalRotationX=float(np.float32(math.sin(float(T))) * np.float32(.5)),
+                _FractalRotationY=float(np.float32(math.sin(float(T * np.float32(1.414)))) * np.float32(.5)),
+                _FractalRotationZ=float(np.float32(math.sin(float(T * np.float32(1.618)))) * np.float32(.5)),
+                _Time=f32([T / 20, T, 2 * T, 3 * T]))
+    a1, a2 = f32([0, 0, 0, 0]), f32([0, 0, 0, 0])
+    l.rmo_scene(uni_a.ref, fp(p), fp(a1))
+    l.rmo_scene(oracle.Uniforms(anim).ref, fp(p), fp(a2))
+    assert a1.tolist() == a2.tolist()
+    assert a1.tolist() != out.tolist()
