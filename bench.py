@@ -594,6 +594,48 @@ def run_single(args) -> None:
             mf.close(); msm.close()
             del smap
 
+
+        # ---- the host-pointer entry points (PCIe-inclusive; never the headline): what RaymarchingNative.cs calls ----------
+        import ctypes as C
+        mh = default_material(1920, 1080)
+        npx = 1920 * 1080
+        hb = [[lib.rm_host_alloc(mh.handle, npx * 4), lib.rm_host_alloc(mh.handle, npx * 4), lib.rm_host_alloc(mh.handle, npx)] for _ in range(2)]
+        hs = [lib.rm_host_alloc(mh.handle, npx * 4), lib.rm_host_alloc(mh.handle, npx * 4)]       # _MainTex and the depth texture
+        if all(all(x) for x in hb) and all(hs):
+            C.memset(hs[0], 64, npx * 4)
+            np.ctypeslib.as_array(C.cast(hs[1], C.POINTER(C.c_float)), shape=(npx,))[:] = 1000.0
+            nh = 60
+
+            def host_loop(with_inputs, pipelined):
+                a, b = (hs[0], hs[1]) if with_inputs else (None, None)
+                for _ in range(5):
+                    mh._ck(lib.rm_blit(mh.handle, a, b, hb[0][0], hb[0][1], hb[0][2], 1920, 1080))
+                t0_ = time.perf_counter()
+                if not pipelined:
+                    for _ in range(nh):
+                        mh._ck(lib.rm_blit(mh.handle, a, b, hb[0][0], hb[0][1], hb[0][2], 1920, 1080))
+                else:
+                    tk = [C.c_longlong(), C.c_longlong()]
+                    for i_ in range(nh):
+                        o = hb[i_ & 1]
+                        mh._ck(lib.rm_blit_async(mh.handle, a, b, o[0], o[1], o[2], 1920, 1080, C.byref(tk[i_ & 1])))
+                        if i_ > 0:
+                            mh._ck(lib.rm_blit_wait(mh.handle, tk[(i_ - 1) & 1].value))      # frame i-1 is shown while frame i marches
+                    mh._ck(lib.rm_blit_wait(mh.handle, tk[(nh - 1) & 1].value))
+                return (time.perf_counter() - t0_) / nh * 1e3
+
+            sec["host_pointer_blit_1080p"] = {
+                "what": "1920x1080 through the host-pointer entry points into rm_host_alloc memory, ms per frame, PCIe copies included: "
+                        "rm_blit (synchronous) against rm_blit_async / rm_blit_wait with two frames in flight; without inputs, and with "
+                        "_MainTex + the depth texture uploaded every frame (8 B/pixel up, 9 B/pixel down)",
+                "rm_blit_ms": host_loop(False, False), "rm_blit_async_pipelined_ms": host_loop(False, True),
+                "rm_blit_with_src_and_depth_ms": host_loop(True, False), "rm_blit_async_pipelined_with_src_and_depth_ms": host_loop(True, True),
+                "kernel_only_ms": sec["default_1080p"]["ms_per_step"]}
+        for x in [y for o in hb for y in o] + hs:
+            if x:
+                lib.rm_host_free(mh.handle, x)
+        mh.close()
+
         # ---- the other scene() bodies and one frame with frag's optional lines, 1080p close-ups ---------------------------
         def closeup_material(body, extra=None):
             mm = Material(device=0)

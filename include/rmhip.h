@@ -136,6 +136,19 @@ int rm_set_primitives(rm_ctx *ctx, const rm_primitive *prims, int n);
 int rm_blit(rm_ctx *ctx, const uint8_t *src_rgba8, const float *scene_depth,
             uint8_t *dst_rgba8, float *dst_depth, uint8_t *dst_hit, int w, int h);
 
+/* rm_blit in two halves, for a caller that renders frame after frame into host memory (no counterpart in the reference,
+ * whose Graphics.Blit is queued to Unity's render thread and never waited for by the script): rm_blit_async queues the
+ * uploads of src / scene_depth, the march and the copies of the outputs back, and returns a ticket; rm_blit_wait(ticket)
+ * returns once that call's outputs are in the caller's buffers, which hold exactly what rm_blit would have written.  Two
+ * calls may be in flight: the copies back of one frame run beside the march of the next (two staging sets in HBM, an
+ * upload and a download stream).  A third call first waits, in stream order, for the one two calls earlier.  The
+ * caller's buffers of a call belong to the library until rm_blit_wait for its ticket (or for a later one) has returned;
+ * they should come from rm_host_alloc -- into pageable memory the copies are staged by the runtime and overlap little.
+ * Properties are read when rm_blit_async is called.  rm_blit, the depth passes and rm_destroy wait for calls in flight. */
+int rm_blit_async(rm_ctx *ctx, const uint8_t *src_rgba8, const float *scene_depth,
+                  uint8_t *dst_rgba8, float *dst_depth, uint8_t *dst_hit, int w, int h, long long *ticket);
+int rm_blit_wait(rm_ctx *ctx, long long ticket);
+
 /* Page-locked host memory for the images of the host-pointer entry points.  No counterpart in the reference (Unity owns
  * its render targets).  rm_blit works with any host pointer; into pageable memory the runtime stages every copy (measured
  * 1.12 ms per 1920x1080 frame), into memory from rm_host_alloc the copies run at PCIe rate.  Free with rm_host_free

@@ -59,6 +59,8 @@ SYMBOLS = [
     ("rm_host_alloc", _P, [_P, C.c_size_t]),
     ("rm_host_free", None, [_P, _P]),
     ("rm_blit", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int]),
+    ("rm_blit_async", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.POINTER(C.c_longlong)]),
+    ("rm_blit_wait", C.c_int, [_P, C.c_longlong]),
     ("rm_blit_device", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     ("rm_blit_steps", C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int]),
     ("rm_blit_steps_device", C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),

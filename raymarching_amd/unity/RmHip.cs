@@ -51,6 +51,10 @@ public static class RmHip
 
     [DllImport(Lib)] public static extern int rm_blit(IntPtr ctx, IntPtr srcRgba8, IntPtr sceneDepth,
                                                       IntPtr dstRgba8, IntPtr dstDepth, IntPtr dstHit, int w, int h);
+    // rm_blit in two halves: queue frame N + 1, then wait for frame N (its copies back overlap the next march)
+    [DllImport(Lib)] public static extern int rm_blit_async(IntPtr ctx, IntPtr srcRgba8, IntPtr sceneDepth,
+                                                            IntPtr dstRgba8, IntPtr dstDepth, IntPtr dstHit, int w, int h, out long ticket);
+    [DllImport(Lib)] public static extern int rm_blit_wait(IntPtr ctx, long ticket);
     [DllImport(Lib)] public static extern int rm_blit_device(IntPtr ctx, IntPtr dSrc, IntPtr dSceneDepth,
                                                              IntPtr dRgba8, IntPtr dDepth, IntPtr dHit, int w, int h, IntPtr hipStream);
     [DllImport(Lib)] public static extern int rm_blit_device_noalloc(IntPtr ctx, IntPtr dSrc, IntPtr dSceneDepth,

@@ -894,3 +894,75 @@ def test_host_blit_into_page_locked_buffers(oracle, torch_cuda):
             lib.rm_host_free(mat.handle, b)
         assert lib.rm_host_alloc(mat.handle, 0) is None
     assert_frame_equal(got, ref, "pinned host buffers")
+
+
+@pytest.mark.parametrize("name", ["default_640x360", "default_src_depth_333x187", "orbit_k23_480x270"])
+def test_async_host_blit_equals_rm_blit(oracle, torch_cuda, name):
+    """rm_blit_async + rm_blit_wait: frames queued back to back (two in flight, the copies back of one beside the march of
+    the next) arrive byte for byte as rm_blit delivers them, in page-locked and in pageable buffers, also when sizes and
+    the presence of a source image change from call to call and when synchronous calls are mixed in"""
+    import ctypes as C
+    from raymarching_amd import Material, native
+    case = cases.BY_NAME[name]
+    ref = cases.oracle_run(case, oracle)
+    small = cases.BY_NAME["tiny_17x3"]
+    ref_small = cases.oracle_run(small, oracle)
+    lib = native.lib()
+    with Material() as mat:
+        src, sd = case.bind(mat)
+        n = case.w * case.h
+
+        def view(p, count, dt):
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(dt)), shape=(count,))
+
+        sets = []
+        for pinned in (True, True, False):
+            if pinned:
+                pr, pd, ph = (lib.rm_host_alloc(mat.handle, n * 4), lib.rm_host_alloc(mat.handle, n * 4), lib.rm_host_alloc(mat.handle, n))
+                assert pr and pd and ph
+                sets.append((pr, pd, ph, view(pr, n * 4, C.c_uint8), view(pd, n, C.c_float), view(ph, n, C.c_uint8), True))
+            else:
+                a, b, c_ = np.zeros(n * 4, np.uint8), np.zeros(n, np.float32), np.zeros(n, np.uint8)
+                sets.append((a.ctypes.data, b.ctypes.data, c_.ctypes.data, a, b, c_, False))
+        sp = src.ctypes.data if src is not None else None
+        dp = sd.ctypes.data if sd is not None else None
+        tickets = []
+        for i in range(7):
+            pr, pd, ph, ar, ad, ah, _ = sets[i % 3]
+            if i >= 2:                                      # frame i - 2 must be complete before its buffers are reused (i % 3 != (i - 2) % 3,
+                mat._ck(lib.rm_blit_wait(mat.handle, tickets[i - 2]))          # but at most two may be in flight anyway)
+                _, _, _, br, bd, bh, _ = sets[(i - 2) % 3]
+                got = {"rgba": br.reshape(case.h, case.w, 4).copy(), "depth": bd.reshape(case.h, case.w).copy(), "hit": bh.reshape(case.h, case.w).copy()}
+                assert_frame_equal(got, ref, f"{name} async frame {i - 2}")
+                br[:] = 0; bd[:] = 0; bh[:] = 0
+            t = C.c_longlong(-1)
+            mat._ck(lib.rm_blit_async(mat.handle, sp, dp, pr, pd, ph, case.w, case.h, C.byref(t)))
+            assert t.value == i
+            tickets.append(t.value)
+        assert mat.stats()["n_hit"] == int(ref["hit"].sum())
+        for i in (5, 6):
+            mat._ck(lib.rm_blit_wait(mat.handle, tickets[i]))
+            _, _, _, br, bd, bh, _ = sets[i % 3]
+            got = {"rgba": br.reshape(case.h, case.w, 4).copy(), "depth": bd.reshape(case.h, case.w).copy(), "hit": bh.reshape(case.h, case.w).copy()}
+            assert_frame_equal(got, ref, f"{name} async frame {i}")
+        mat._ck(lib.rm_blit_wait(mat.handle, tickets[0]))               # long done
+        assert lib.rm_blit_wait(mat.handle, 99) == native.RM_E_ARG
+        # a smaller frame without source image queued right behind a large one with, then a synchronous call
+        pr, pd, ph, ar, ad, ah, _ = sets[0]
+        t0, t1 = C.c_longlong(), C.c_longlong()
+        mat._ck(lib.rm_blit_async(mat.handle, sp, dp, pr, pd, ph, case.w, case.h, C.byref(t0)))
+        small.bind(mat)
+        qr, qd, qh = np.zeros((small.h, small.w, 4), np.uint8), np.zeros((small.h, small.w), np.float32), np.zeros((small.h, small.w), np.uint8)
+        mat._ck(lib.rm_blit_async(mat.handle, None, None, qr.ctypes.data, qd.ctypes.data, qh.ctypes.data, small.w, small.h, C.byref(t1)))
+        sr, sdp, sh = np.zeros_like(qr), np.zeros_like(qd), np.zeros_like(qh)
+        mat._ck(lib.rm_blit(mat.handle, None, None, sr.ctypes.data, sdp.ctypes.data, sh.ctypes.data, small.w, small.h))   # waits for both
+        assert_frame_equal({"rgba": sr, "depth": sdp, "hit": sh}, ref_small, "sync after async")
+        mat._ck(lib.rm_blit_wait(mat.handle, t1.value))
+        assert_frame_equal({"rgba": qr, "depth": qd, "hit": qh}, ref_small, "small async")
+        mat._ck(lib.rm_blit_wait(mat.handle, t0.value))
+        got = {"rgba": ar.reshape(case.h, case.w, 4).copy(), "depth": ad.reshape(case.h, case.w).copy(), "hit": ah.reshape(case.h, case.w).copy()}
+        assert_frame_equal(got, ref, "large async before the small one")
+        for pr, pd, ph, _, _, _, pinned in sets:
+            if pinned:
+                for p_ in (pr, pd, ph):
+                    lib.rm_host_free(mat.handle, p_)
