@@ -140,8 +140,8 @@ int rm_blit(rm_ctx *ctx, const uint8_t *src_rgba8, const float *scene_depth,
  * whose Graphics.Blit is queued to Unity's render thread and never waited for by the script): rm_blit_async queues the
  * uploads of src / scene_depth, the march and the copies of the outputs back, and returns a ticket; rm_blit_wait(ticket)
  * returns once that call's outputs are in the caller's buffers, which hold exactly what rm_blit would have written.  Two
- * calls may be in flight: the copies back of one frame run beside the march of the next (two staging sets in HBM, an
- * upload and a download stream).  A third call first waits, in stream order, for the one two calls earlier.  The
+ * calls may be in flight: the copies back of one frame run beside the uploads and the march of the next (two staging sets in
+ * HBM, each with a stream of its own).  A third call queues, in stream order, behind the one two calls earlier.  The
  * caller's buffers of a call belong to the library until rm_blit_wait for its ticket (or for a later one) has returned;
  * they should come from rm_host_alloc -- into pageable memory the copies are staged by the runtime and overlap little.
  * Properties are read when rm_blit_async is called.  rm_blit, the depth passes and rm_destroy wait for calls in flight. */

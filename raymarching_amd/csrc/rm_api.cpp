@@ -109,12 +109,13 @@ struct rm_ctx {
     unsigned last_leaf_waves = 0;  // waves of the last launch that wrote leaf statistics (0: it was no culling launch)
     void *d_stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // src, sdepth, rgba, depth, hit, steps
     size_t d_stage_cap[6] = {0, 0, 0, 0, 0, 0};
-    // rm_blit_async: a second staging set (the first is d_stage), an upload and a download stream beside `stream`,
-    // and per set the events "kernel done" (inputs free, outputs ready) and "outputs in the caller's buffers"
+    // rm_blit_async: two staging sets, each with a stream of its own that runs uploads, march and copies back of the calls
+    // that use the set, in order (set 0 is d_stage on `stream`, shared with the synchronous entry points); per set the
+    // event "outputs are in the caller's buffers"
     void *d_stage_b[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t d_stage_b_cap[6] = {0, 0, 0, 0, 0, 0};
-    hipStream_t up_stream = nullptr, down_stream = nullptr;
-    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_kernel[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    hipStream_t stream_b = nullptr;
+    hipEvent_t ev_done[2] = {nullptr, nullptr};
     bool async_used[2] = {false, false};    // the set has a call whose events were recorded
     long long async_issued = 0;             // tickets handed out so far (ticket t uses set t & 1)
 
@@ -919,13 +920,8 @@ void rm_destroy(rm_ctx *c) {
         for (int k = 0; k < 2; k++) if (c->async_used[k]) (void)hipEventSynchronize(c->ev_done[k]);
         for (int i = 0; i < 6; i++) if (c->d_stage[i]) (void)hipFree(c->d_stage[i]);
         for (int i = 0; i < 6; i++) if (c->d_stage_b[i]) (void)hipFree(c->d_stage_b[i]);
-        for (int k = 0; k < 2; k++) {
-            if (c->ev_up[k]) (void)hipEventDestroy(c->ev_up[k]);
-            if (c->ev_kernel[k]) (void)hipEventDestroy(c->ev_kernel[k]);
-            if (c->ev_done[k]) (void)hipEventDestroy(c->ev_done[k]);
-        }
-        if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
-        if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
+        for (int k = 0; k < 2; k++) if (c->ev_done[k]) (void)hipEventDestroy(c->ev_done[k]);
+        if (c->stream_b) { (void)hipStreamSynchronize(c->stream_b); (void)hipStreamDestroy(c->stream_b); }
         if (c->d_prims) (void)hipFree(c->d_prims);
         if (c->d_views) (void)hipFree(c->d_views);
         if (c->d_leaf_stats) (void)hipFree(c->d_leaf_stats);
@@ -1214,16 +1210,11 @@ static int blit_host_common(rm_ctx *c, const uint8_t *src, const float *sdepth, 
     return RM_OK;
 }
 
-// first use of rm_blit_async: its two copy streams and six events
+// first use of rm_blit_async: the second set's stream and the two events the host waits on
 static int ensure_async(rm_ctx *c) {
-    if (!c->up_stream) RM_HIP(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
-    if (!c->down_stream) RM_HIP(c, hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking));
-    for (int k = 0; k < 2; k++) {
-        if (!c->ev_up[k]) RM_HIP(c, hipEventCreateWithFlags(&c->ev_up[k], RM_EVENT_FLAGS));
-        if (!c->ev_kernel[k]) RM_HIP(c, hipEventCreateWithFlags(&c->ev_kernel[k], RM_EVENT_FLAGS));
-        // the host waits on this one and then reads what the copies wrote: it keeps the system-scope fence
-        if (!c->ev_done[k]) RM_HIP(c, hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming));
-    }
+    if (!c->stream_b) RM_HIP(c, hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
+    // the host waits on these and then reads what the copies wrote: they keep the system-scope fence
+    for (int k = 0; k < 2; k++) if (!c->ev_done[k]) RM_HIP(c, hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming));
     return RM_OK;
 }
 
@@ -1237,40 +1228,33 @@ int rm_blit_async(rm_ctx *c, const uint8_t *src, const float *sdepth, uint8_t *r
     RM_HIP(c, ds.enter(c->device));
     if ((rc = ensure_device(c))) return rc;
     if ((rc = ensure_async(c))) return rc;
+    // Calls alternate between the two sets.  Everything of one call -- uploads, march, copies back -- is queued on its
+    // set's stream in that order, so a set's buffers are reused in stream order without an event; across the sets only
+    // the marches are ordered (every launch waits for the context's previous one, launch()).  The copies back of call N
+    // therefore run beside the uploads and the march of call N + 1.
     const int k = (int)(c->async_issued & 1);
     void **st = k ? c->d_stage_b : c->d_stage;
     size_t *cap = k ? c->d_stage_b_cap : c->d_stage_cap;
+    hipStream_t s = k ? c->stream_b : c->stream;
     const size_t n = (size_t)w * (size_t)h;
     const size_t need[5] = {src ? n * 4 : 0, sdepth ? n * 4 : 0, rgba ? n * 4 : 0, depth ? n * 4 : 0, hit ? n : 0};
     bool grow = false;
     for (int i = 0; i < 5; i++) grow = grow || need[i] > cap[i];
     if (grow) {
-        // growing frees the old buffers: whatever still uses this set has to be through (two calls earlier at most)
-        if (c->async_used[k]) RM_HIP(c, hipEventSynchronize(c->ev_done[k]));
+        // growing frees the old buffers: whatever still uses this set has to be through
+        RM_HIP(c, hipStreamSynchronize(s));
         if ((rc = wait_for_last(c))) return rc;
         for (int i = 0; i < 5; i++) if (need[i] && (rc = ensure_cap(c, &st[i], &cap[i], need[i]))) return rc;
     }
-    // uploads: once the set's previous kernel has read its inputs
-    if (src || sdepth) {
-        if (c->async_used[k]) RM_HIP(c, hipStreamWaitEvent(c->up_stream, c->ev_kernel[k], 0));
-        else if ((rc = order_after_last(c, c->up_stream))) return rc;         // a synchronous call may have used set 0 last
-        if (src) RM_HIP(c, hipMemcpyAsync(st[0], src, n * 4, hipMemcpyHostToDevice, c->up_stream));
-        if (sdepth) RM_HIP(c, hipMemcpyAsync(st[1], sdepth, n * 4, hipMemcpyHostToDevice, c->up_stream));
-        RM_HIP(c, hipEventRecord(c->ev_up[k], c->up_stream));
-        RM_HIP(c, hipStreamWaitEvent(c->stream, c->ev_up[k], 0));
-    }
-    // the kernel: once the set's previous outputs have left for the host
-    if (c->async_used[k]) RM_HIP(c, hipStreamWaitEvent(c->stream, c->ev_done[k], 0));
+    if (src) RM_HIP(c, hipMemcpyAsync(st[0], src, n * 4, hipMemcpyHostToDevice, s));
+    if (sdepth) RM_HIP(c, hipMemcpyAsync(st[1], sdepth, n * 4, hipMemcpyHostToDevice, s));
     rc = blit_device_common(c, src ? st[0] : nullptr, sdepth ? st[1] : nullptr, rgba ? st[2] : nullptr, depth ? st[3] : nullptr,
-                            hit ? st[4] : nullptr, nullptr, w, h, h, 0, 1, c->stream);
+                            hit ? st[4] : nullptr, nullptr, w, h, h, 0, 1, s);
     if (rc) return rc;
-    RM_HIP(c, hipEventRecord(c->ev_kernel[k], c->stream));
-    // the copies back, beside the next call's kernel
-    RM_HIP(c, hipStreamWaitEvent(c->down_stream, c->ev_kernel[k], 0));
-    if (rgba)  RM_HIP(c, hipMemcpyAsync(rgba, st[2], n * 4, hipMemcpyDeviceToHost, c->down_stream));
-    if (depth) RM_HIP(c, hipMemcpyAsync(depth, st[3], n * 4, hipMemcpyDeviceToHost, c->down_stream));
-    if (hit)   RM_HIP(c, hipMemcpyAsync(hit, st[4], n, hipMemcpyDeviceToHost, c->down_stream));
-    RM_HIP(c, hipEventRecord(c->ev_done[k], c->down_stream));
+    if (rgba)  RM_HIP(c, hipMemcpyAsync(rgba, st[2], n * 4, hipMemcpyDeviceToHost, s));
+    if (depth) RM_HIP(c, hipMemcpyAsync(depth, st[3], n * 4, hipMemcpyDeviceToHost, s));
+    if (hit)   RM_HIP(c, hipMemcpyAsync(hit, st[4], n, hipMemcpyDeviceToHost, s));
+    RM_HIP(c, hipEventRecord(c->ev_done[k], s));
     c->async_used[k] = true;
     *ticket = c->async_issued++;
     return RM_OK;

@@ -1,9 +1,15 @@
 // RaymarchingNative.cs -- plugin-backed counterpart of the project's Raymarching image effect.
 // Attach to the camera INSTEAD of Raymarching.cs.  Where that script binds five matrices on
-// Raymarching.mat and calls Graphics.Blit (its OnRenderImage), this one binds the same names
-// on an rm_ctx and calls rm_blit; the marched frame comes back as RGBA8 and is shown with a
-// plain texture blit.  The float sliders still live on the Unity material asset and are
-// mirrored into the plugin each frame, so the inspector keeps working.
+// Raymarching.mat and calls Graphics.Blit(source, destination, mat) (its OnRenderImage), this one
+// binds the same names on an rm_ctx and calls rm_blit with the same two inputs the shader reads:
+// the source image (_MainTex: what miss pixels show, Raymarching.shader:151,197-202) and the
+// camera's depth texture as linear eye depth (Raymarching.shader:154; the script asks for it with
+// depthTextureMode = Depth, Raymarching.cs:21), so the skybox stays behind the primitives and meshes
+// keep occluding the march.  The marched frame comes back as RGBA8 and is shown with a plain
+// texture blit.  The float sliders still live on the Unity material asset and are mirrored into
+// the plugin each frame, so the inspector keeps working.
+//
+// Never compiled (no C# toolchain where this library is built); Unity 2018.3 API names only.
 using System;
 using System.Runtime.InteropServices;
 using UnityEngine;
@@ -16,6 +22,9 @@ public class RaymarchingNative : MonoBehaviour
     public Transform[] transforms;       // the four "Position N" objects
     public Light sun;                    // directional light whose direction becomes _WorldSpaceLightPos0
     public int hipDevice = 0;
+    public bool readSource = true;       // pass the source image and the depth texture, as Graphics.Blit(source, ...) does
+    public bool pipelined = false;       // rm_blit_async: show frame N - 1 while frame N marches (one frame of latency)
+    public Shader linearDepthShader;     // RmLinearEyeDepth.shader (Hidden/RmLinearEyeDepth)
 
     static readonly string[] FloatNames = {
         "_MaxSteps", "_MaxDist", "_StepFactor", "_ContactThreshold", "_NormalSampleScale",
@@ -24,13 +33,19 @@ public class RaymarchingNative : MonoBehaviour
 
     Camera cam;
     RmMaterial native;
-    Texture2D frame;
-    IntPtr pixels, depth;          // page-locked buffers from rm_host_alloc: the copies back run at PCIe rate
-    int frameBytes;
+    Texture2D frame, srcCopy, depthCopy;
+    RenderTexture depthRT;
+    Material linearDepthMat;
+    // page-locked buffers from rm_host_alloc (the copies run at PCIe rate), two sets of inputs and outputs: a set belongs to
+    // the library from rm_blit_async until rm_blit_wait for its ticket has returned
+    IntPtr[] pixels = new IntPtr[2], depth = new IntPtr[2], srcPixels = new IntPtr[2], srcDepth = new IntPtr[2];
+    long[] tickets = { -1, -1 };
+    int frameBytes, frameIndex;
 
     void OnEnable()
     {
         cam = GetComponent<Camera>();
+        cam.depthTextureMode = DepthTextureMode.Depth;          // Raymarching.cs:21
         native = new RmMaterial(hipDevice);
     }
 
@@ -44,10 +59,15 @@ public class RaymarchingNative : MonoBehaviour
     {
         if (native != null)
         {
-            if (pixels != IntPtr.Zero) RmHip.rm_host_free(native.Ctx, pixels);
-            if (depth != IntPtr.Zero) RmHip.rm_host_free(native.Ctx, depth);
+            for (int k = 0; k < 2; k++)
+            {
+                if (tickets[k] >= 0) RmHip.rm_blit_wait(native.Ctx, tickets[k]);      // the library still owns the buffers until then
+                foreach (var p in new[] { pixels[k], depth[k], srcPixels[k], srcDepth[k] })
+                    if (p != IntPtr.Zero) RmHip.rm_host_free(native.Ctx, p);
+            }
         }
-        pixels = IntPtr.Zero; depth = IntPtr.Zero;
+        for (int k = 0; k < 2; k++) { pixels[k] = depth[k] = srcPixels[k] = srcDepth[k] = IntPtr.Zero; tickets[k] = -1; }
+        if (depthRT != null) { depthRT.Release(); depthRT = null; }
     }
 
     void Ensure(int w, int h)
@@ -55,10 +75,40 @@ public class RaymarchingNative : MonoBehaviour
         if (frame != null && frame.width == w && frame.height == h) return;
         Release();
         frame = new Texture2D(w, h, TextureFormat.RGBA32, false, true);   // linear: the project is in Gamma space
+        srcCopy = new Texture2D(w, h, TextureFormat.RGBA32, false, true);
+        depthCopy = new Texture2D(w, h, TextureFormat.RFloat, false, true);
+        depthRT = new RenderTexture(w, h, 0, RenderTextureFormat.RFloat, RenderTextureReadWrite.Linear);
         frameBytes = w * h * 4;
-        pixels = RmHip.rm_host_alloc(native.Ctx, (UIntPtr)(ulong)frameBytes);
-        depth = RmHip.rm_host_alloc(native.Ctx, (UIntPtr)(ulong)frameBytes);
-        if (pixels == IntPtr.Zero || depth == IntPtr.Zero) throw new InvalidOperationException("librmhip: " + RmHip.LastError(native.Ctx));
+        for (int k = 0; k < 2; k++)
+        {
+            pixels[k] = RmHip.rm_host_alloc(native.Ctx, (UIntPtr)(ulong)frameBytes);
+            depth[k] = RmHip.rm_host_alloc(native.Ctx, (UIntPtr)(ulong)frameBytes);
+            srcPixels[k] = RmHip.rm_host_alloc(native.Ctx, (UIntPtr)(ulong)frameBytes);
+            srcDepth[k] = RmHip.rm_host_alloc(native.Ctx, (UIntPtr)(ulong)frameBytes);
+            if (pixels[k] == IntPtr.Zero || depth[k] == IntPtr.Zero || srcPixels[k] == IntPtr.Zero || srcDepth[k] == IntPtr.Zero)
+                throw new InvalidOperationException("librmhip: " + RmHip.LastError(native.Ctx));
+        }
+    }
+
+    // The two textures frag samples, read back into the page-locked buffers of set k: _MainTex as RGBA8 (row 0 = bottom row,
+    // the order ReadPixels delivers and rm_blit expects) and the depth texture as linear eye depth,
+    // Linear01Depth(tex2D(_CameraDepthTexture, uv)) * _ProjectionParams.z (Raymarching.shader:154), one float per pixel.
+    void ReadInputs(RenderTexture src, int k)
+    {
+        int w = src.width, h = src.height;
+        var prev = RenderTexture.active;
+        RenderTexture.active = src;
+        srcCopy.ReadPixels(new Rect(0, 0, w, h), 0, 0, false);
+        byte[] raw = srcCopy.GetRawTextureData();
+        Marshal.Copy(raw, 0, srcPixels[k], frameBytes);
+        if (linearDepthMat == null)
+            linearDepthMat = new Material(linearDepthShader != null ? linearDepthShader : Shader.Find("Hidden/RmLinearEyeDepth"));
+        Graphics.Blit(null, depthRT, linearDepthMat);               // the pass reads the global _CameraDepthTexture
+        RenderTexture.active = depthRT;
+        depthCopy.ReadPixels(new Rect(0, 0, w, h), 0, 0, false);
+        raw = depthCopy.GetRawTextureData();
+        Marshal.Copy(raw, 0, srcDepth[k], frameBytes);
+        RenderTexture.active = prev;
     }
 
     // un-normalised view-space rays through the four image corners, one per matrix row
@@ -106,10 +156,29 @@ public class RaymarchingNative : MonoBehaviour
         Color bg = cam.backgroundColor;
         native.SetVector("_BackgroundColor", new Vector4(bg.r, bg.g, bg.b, 1f));
 
-        // no meshes in front of the march: no source image, no depth texture
-        RmHip.Check(native.Ctx, RmHip.rm_blit(native.Ctx, IntPtr.Zero, IntPtr.Zero,
-                                             pixels, depth, IntPtr.Zero, w, h));
-        frame.LoadRawTextureData(pixels, frameBytes);      // row 0 = bottom row, as Texture2D expects
+        int k = frameIndex & 1;
+        IntPtr inPixels = IntPtr.Zero, inDepth = IntPtr.Zero;
+        if (readSource)
+        {
+            if (tickets[k] >= 0) { RmHip.Check(native.Ctx, RmHip.rm_blit_wait(native.Ctx, tickets[k])); tickets[k] = -1; }
+            ReadInputs(src, k);
+            inPixels = srcPixels[k]; inDepth = srcDepth[k];
+        }
+        int show = k;
+        if (!pipelined)
+        {
+            RmHip.Check(native.Ctx, RmHip.rm_blit(native.Ctx, inPixels, inDepth, pixels[k], depth[k], IntPtr.Zero, w, h));
+        }
+        else
+        {
+            // queue this frame, then wait for the previous one: its copies back ran beside this frame's uploads and march
+            if (tickets[k] >= 0) RmHip.Check(native.Ctx, RmHip.rm_blit_wait(native.Ctx, tickets[k]));
+            RmHip.Check(native.Ctx, RmHip.rm_blit_async(native.Ctx, inPixels, inDepth, pixels[k], depth[k], IntPtr.Zero, w, h, out tickets[k]));
+            if (tickets[k ^ 1] >= 0) { RmHip.Check(native.Ctx, RmHip.rm_blit_wait(native.Ctx, tickets[k ^ 1])); tickets[k ^ 1] = -1; show = k ^ 1; }
+            else { RmHip.Check(native.Ctx, RmHip.rm_blit_wait(native.Ctx, tickets[k])); tickets[k] = -1; }      // the very first frame
+        }
+        frameIndex++;
+        frame.LoadRawTextureData(pixels[show], frameBytes);      // row 0 = bottom row, as Texture2D expects
         frame.Apply(false);
         Graphics.Blit(frame, dest);
     }
