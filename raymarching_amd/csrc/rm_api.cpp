@@ -439,13 +439,20 @@ int build_params(rm_ctx *c, RmParams *U, hipStream_t stream) {
     U->n_poses = 1;
 
     int flags = RM_SF_IDENT_ROT | RM_SF_UNIT_SCALE | RM_SF_RCP;
+    bool lipschitz = false;
     if (c->prims.empty()) {
         rm_primitive lp[4];
         legacy_prims(c, lp);
+        lipschitz = getf(c, "_RmPairSkip", 1.0f) != 0.0f;
         for (int i = 0; i < 4; i++) {
             int pf = 0;
             U->prims4[i] = prepare_prim(lp[i], &pf);
             flags &= pf;
+            // a primitive's distance changes no faster than its argument moves only for finite, positive scales and
+            // a quaternion that does not stretch (|q| within 1e-3 of 1: rotate() scales lengths by |q|^2)
+            for (int k = 0; k < 3; k++) lipschitz = lipschitz && std::isfinite(lp[i].scale[k]) && lp[i].scale[k] > 0.0f;
+            const float q2 = lp[i].quat[0] * lp[i].quat[0] + lp[i].quat[1] * lp[i].quat[1] + lp[i].quat[2] * lp[i].quat[2] + lp[i].quat[3] * lp[i].quat[3];
+            lipschitz = lipschitz && q2 >= 0.999f && q2 <= 1.001f;
         }
         U->n_prims = 0;
     } else {
@@ -537,7 +544,7 @@ int build_params(rm_ctx *c, RmParams *U, hipStream_t stream) {
         U->f_pow3 = (float)std::pow(3.0, -12.0);
         for (int i = 0; i < 16; i++) U->f_pows[i] = (float)std::pow((double)scale, -(double)i);
     }
-    U->scene_flags = flags;
+    U->scene_flags = flags | (lipschitz ? RM_SF_LIPSCHITZ : 0);
     U->fx_flags = (getf(c, "_RmStepHeat", 0.0f) != 0.0f ? RM_FX_STEP_HEAT : 0u) |
                   (getf(c, "_RmVolumetricLight", 0.0f) != 0.0f ? RM_FX_VOLUMETRIC : 0u) |
                   (getf(c, "_RmBounce", 0.0f) != 0.0f ? RM_FX_BOUNCE : 0u) |

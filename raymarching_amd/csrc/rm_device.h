@@ -43,6 +43,8 @@ enum : int32_t {
     RM_SF_UNIT_SCALE = 2,
     RM_SF_RCP        = 4,
     RM_SF_CSG        = 8,   // some primitive carries an op bit (smax node or negated distance)
+    RM_SF_LIPSCHITZ  = 16,  // 4-slot scene: every scale is finite and positive, so every primitive's distance (and any smin of
+                            // them) changes by at most the distance the sample point moves
 };
 
 #define RM_TYPE_MASK 0xff

@@ -87,6 +87,9 @@ template <class S> struct rm_is_fast { static constexpr bool value = false; };
 // _ShadowMap instead of the soft-shadow march (4).  The per-tile code then drops the uniform branches (and the scalar
 // registers their conditions occupy) that the other launch shapes need.  0 = any shape.
 template <class S> struct rm_shape { static constexpr int value = 0; };
+// A scene type whose root is smin(left(p), right(p)) with 1-Lipschitz operands may offer the two halves separately: the
+// soft-shadow march then skips the left half while it provably lies .5 above the right one (rm_getshadow).
+template <class S> struct rm_pair_skip { static constexpr bool value = false; };
 
 // scale handling chosen per scene on the host
 enum { RM_SCL_UNIT = 0, RM_SCL_RCP = 1, RM_SCL_DIV = 2 };
@@ -239,6 +242,10 @@ struct Scene4 {
         return rm_smin_w(rm_smin_w(o0, o1), rm_smin_w(o2, o3));
     }
     RM_DI float wm(V3 p) const { return w(p); }      // the evaluation the two march loops use (a kernel may relax it)
+    // the two operands of the root smin (cginc:363): w(p) == rm_smin_w(left(p), right(p)), operation for operation
+    RM_DI float left(V3 p) const { return rm_smin_w(rm_prim_typed<ROT, SCL>(P0, 0, p, tiny), rm_prim_typed<ROT, SCL>(P1, 1, p, tiny)); }
+    RM_DI float right(V3 p) const { return rm_smin_w(rm_prim_typed<ROT, SCL>(P2, 2, p, tiny), rm_prim_typed<ROT, SCL>(P3, 3, p, tiny)); }
+    RM_DI bool lipschitz() const { return (U.scene_flags & RM_SF_LIPSCHITZ) != 0; }
     RM_DI V4 full(V3 p) const {
         V4 o[4];
         o[0].w = rm_prim_typed<ROT, SCL>(P0, 0, p, tiny);
@@ -256,6 +263,12 @@ struct Scene4Plain : Scene4<ROT, SCL> {
     RM_DI explicit Scene4Plain(const RmParams &u) : Scene4<ROT, SCL>(u) {}
 };
 template <bool ROT, int SCL, int SHAPE> struct rm_shape<Scene4Plain<ROT, SCL, SHAPE>> { static constexpr int value = SHAPE; };
+// (scenes without per-primitive rotation only: the rotated variants already fill their 256 registers, and the second copy of
+// the right pair's code that the skipping loop needs made them spill inside the march)
+#ifndef RM_NO_PAIR_SKIP
+template <int SCL> struct rm_pair_skip<Scene4<false, SCL>> { static constexpr bool value = true; };
+template <int SCL, int SHAPE> struct rm_pair_skip<Scene4Plain<false, SCL, SHAPE>> { static constexpr bool value = true; };
+#endif
 
 // N-primitive scene from a table in global memory.  Every lane walks the table
 // with the same index, so the loads are wave-uniform and go through the scalar

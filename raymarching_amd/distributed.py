@@ -180,10 +180,10 @@ class _Ticket:
 class TileGather:
     """Gathers finished frames to the root as compact tile records (rm_compact_frames_device): only the 8x8
     tiles that hold a hit pixel travel, everything else the root reconstructs from the background it already
-    has (rm_expand_frames_device).  Record counts differ per rank and per batch, so the exchange is one small
-    count all-gather on `count_group` (host tensors over gloo; device tensors if that group is RCCL too) followed by
-    point-to-point transfers of exactly
-    count records from every peer to the root (`group`: RCCL over xGMI on GPUs, each peer on its own link).
+    has (rm_expand_frames_device).  Record counts differ per rank and per batch, so every peer first tells the root its
+    count (one small host message on `count_group`, gloo; the peers do not wait for each other or for the root -- if that
+    group is RCCL too, the counts are all-gathered as device tensors instead), then exactly count records travel
+    point-to-point from every peer to the root (`group`: RCCL over xGMI on GPUs, each peer on its own link).
 
         g = TileGather(compact, capacity_records, like_device, root=0)
         t = g.submit(frames, hit)              # compaction on the current stream; returns at once
@@ -211,6 +211,7 @@ class TileGather:
         self.i = 0
         self.bytes_sent = 0                    # payload bytes this rank has sent (diagnostics)
         self.last_counts: Optional[List[int]] = None
+        self._count_send = None                # (work handle, tensor) of this peer's count message still in flight
 
     def submit(self, frames: torch.Tensor, hit: torch.Tensor, tag=None) -> _Ticket:
         k = self.i % len(self.records)
@@ -231,7 +232,8 @@ class TileGather:
         return t
 
     def complete(self, t: _Ticket, on_received: Optional[Callable[[int, torch.Tensor, int], None]] = None) -> List[int]:
-        """returns the record counts of all ranks for this batch"""
+        """returns the record counts of this batch, indexed by rank: all of them on the root; on a peer its own, -1 for the
+        others (only the root is told)"""
         if t.count_ready is not None:
             t.count_ready.synchronize()
         mine = int(t.count_host.item())
@@ -243,9 +245,21 @@ class TileGather:
                 dist.all_gather(outs, torch.tensor([mine], dtype=torch.int32, device=self.device), group=self.count_group)
                 counts = [int(c) for c in torch.cat(outs).tolist()]
         elif self.world > 1:
-            counts = [torch.zeros(1, dtype=torch.int32) for _ in range(self.world)]
-            dist.all_gather(counts, torch.tensor([mine], dtype=torch.int32), group=self.count_group)
-            counts = [int(c.item()) for c in counts]
+            # Only the root needs the counts: every peer posts its own to the root and goes on (no rendezvous among the
+            # peers, no wait for the slowest rank's batch); the root collects them, in rank order.
+            counts = [-1] * self.world
+            counts[self.rank] = mine
+            if self.rank == self.root:
+                for p in range(self.world):
+                    if p != self.root:
+                        c = torch.zeros(1, dtype=torch.int32)
+                        dist.recv(c, self._global(p, self.count_group), group=self.count_group)
+                        counts[p] = int(c.item())
+            else:
+                if self._count_send is not None:
+                    self._count_send[0].wait()                      # the previous batch's (long gone; frees its tensor)
+                msg = torch.tensor([mine], dtype=torch.int32)
+                self._count_send = (dist.isend(msg, self._global(self.root, self.count_group), group=self.count_group), msg)
         else:
             counts = [mine]
         self.last_counts = counts
@@ -302,10 +316,14 @@ class TileGather:
             transfer()
         return counts
 
-    def _global(self, group_rank: int) -> int:
-        return dist.get_global_rank(self.group, group_rank) if self.group is not None else group_rank
+    def _global(self, group_rank: int, group="data") -> int:
+        g = self.group if group == "data" else group
+        return dist.get_global_rank(g, group_rank) if g is not None else group_rank
 
     def drain(self) -> None:
+        if self._count_send is not None:
+            self._count_send[0].wait()
+            self._count_send = None
         if self.cuda:
             torch.cuda.current_stream(self.device).wait_stream(self.side)
 

@@ -2,12 +2,12 @@
 fractal bodies, optional frag lines, domain operators) through the automatic kernel choice and the persistent kernel,
 every frame compared bit for bit with the CPU oracle.
 
-    python scripts/dev_fuzz_soak.py FIRST_SEED N_SEEDS
+    python tests/dev/dev_fuzz_soak.py FIRST_SEED N_SEEDS
 """
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np                      # noqa: E402

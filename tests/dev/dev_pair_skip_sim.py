@@ -1,0 +1,93 @@
+"""CPU simulation (no GPU) of the exact pair skip in the 4-slot scene: the root of scene() is smin(smin(o0,o1), smin(o2,o3))
+(cginc:363); once the left pair lies .5 above the right one, the root returns the right pair's value bit for bit.  The march keeps
+a lower bound of smin(o0,o1) -- its last evaluated value less the distance travelled since (the scene is 1-Lipschitz) -- and skips
+the pair while that bound stays .51 above the right pair's value for every ray of the wave that is still marching.
+Counts, over a sample of 8x8 tiles of the 1080p frame, the wave steps of the primary and of the shadow marches in which the pair is
+skipped, and checks that the skipping march produces the very same distances."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import rm_oracle as O
+from oracle import numpy_restatement as NP
+from raymarching_amd import Material, Raymarching, scenes
+f = np.float32
+w, h = 1920, 1080
+stride = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+mat = Material()
+Raymarching(scenes.default_camera(w, h), mat, scenes.default_transforms()).bind()
+mat.SetVector("_WorldSpaceLightPos0", scenes.WORLD_SPACE_LIGHT_POS0)
+props = O.props_from_material(mat)
+ref = O.render(O.Uniforms(props), w, h, want_steps=True)
+rdx, rdy, rdz = (a.reshape(h, w) for a in NP.pixel_rays(props, w, h))
+cam = np.asarray(props["_WorldSpaceCameraPos"], dtype=f)
+scene = NP.Scene(props)
+sf, steps_max, depth = f(props["_StepFactor"]), int(props["_MaxSteps"]), f(props["_MaxDist"])
+L = np.asarray(props["_WorldSpaceLightPos0"], dtype=f)[:3]
+
+def march(ox, oy, oz, dx, dy, dz, active, shadow):
+    """returns (wave steps, wave steps with the pair skipped, per-ray evaluation counts, per-ray final dm)"""
+    n = ox.shape[0]
+    dm = np.zeros(n, dtype=f)
+    lb = np.full(n, -np.inf, dtype=f)
+    ln = (np.sqrt(dx * dx + dy * dy + dz * dz) * f(1.000001)).astype(f)
+    steps = skipped = predicted = 0
+    ub = np.full(n, np.inf, dtype=f)          # upper bound of the right pair at the next sample point
+    ev = np.zeros(n, dtype=np.int64)
+    with np.errstate(all="ignore"):
+        for i in range(steps_max):
+            if not active.any():
+                break
+            x, y, z = ox + dx * dm, oy + dy * dm, oz + dz * dm
+            o2, o3 = scene.prim(scene.prims[2], x, y, z), scene.prim(scene.prims[3], x, y, z)
+            s23, _ = NP.smin_w(o2, o3)
+            o0, o1 = scene.prim(scene.prims[0], x, y, z), scene.prim(scene.prims[1], x, y, z)
+            s01, _ = NP.smin_w(o0, o1)
+            full, _ = NP.smin_w(s01, s23)
+            steps += 1
+            # the rule that needs no evaluation at all: bounds of both halves carried from the previous step
+            if bool(np.all((lb - ub >= (np.abs(lb) + np.abs(ub)) * f(1e-4) + f(.51))[active])):
+                predicted += 1
+                assert bool(np.all((s01 - s23 >= f(.5))[active])), "predictive rule wrong"
+            if bool(np.all((lb - s23 >= np.abs(lb) * f(1e-4) + f(.51))[active])):
+                skipped += 1
+                d = s23 + f(0)
+                assert np.array_equal(d[active].view(np.uint32), full[active].view(np.uint32)), "skip changed a bit"
+            else:
+                d = full
+                lb = np.where(active, s01, lb)
+            ev += active
+            inc = np.abs(d) * sf
+            dm = np.where(active, dm + inc, dm)
+            lb = lb - inc * ln
+            ub = s23 + inc * ln
+            active = active & ~(np.abs(d) < dm * f(.0025)) & ~(dm > depth)
+    return steps, skipped, ev, dm, predicted
+
+tot = np.zeros(6)
+th, tw = h // 8, w // 8
+for ty in range(0, th, stride):
+    for tx in range(0, tw, stride):
+        sl = (slice(ty * 8, ty * 8 + 8), slice(tx * 8, tx * 8 + 8))
+        dx, dy, dz = (a[sl].reshape(-1).astype(f) for a in (rdx, rdy, rdz))
+        o = [np.full(64, cam[j], dtype=f) for j in range(3)]
+        sp, kp, ev, dm, pp = march(o[0], o[1], o[2], dx, dy, dz, np.ones(64, dtype=bool), False)
+        assert np.array_equal(ev, ref["steps_p"][sl].reshape(-1)), "primary step counts differ from the oracle's"
+        assert np.array_equal(dm.view(np.uint32), ref["depth"][sl].reshape(-1).view(np.uint32))
+        tot[:2] += [sp, kp]; tot[4] += pp
+        hitm = ref["hit"][sl].reshape(-1) > 0
+        if hitm.any():
+            hx, hy, hz = cam[0] + dx * dm, cam[1] + dy * dm, cam[2] + dz * dm
+            e = f(max(0.0, props["_NormalSampleScale"]))
+            W = lambda x, y, z: scene.eval(x, y, z)[1]
+            rx = W(hx + e, hy, hz) - W(hx - e, hy, hz); ry = W(hx, hy + e, hz) - W(hx, hy - e, hz); rz = W(hx, hy, hz + e) - W(hx, hy, hz - e)
+            with np.errstate(all="ignore"):
+                inv = f(1) / np.sqrt(rx * rx + ry * ry + rz * rz)
+            ct = dm * f(.0025)
+            px, py, pz = hx + (rx * inv * ct) * f(2), hy + (ry * inv * ct) * f(2), hz + (rz * inv * ct) * f(2)
+            ss, ks, ev, _, ps = march(px, py, pz, np.full(64, L[0], f), np.full(64, L[1], f), np.full(64, L[2], f), hitm.copy(), True)
+            assert np.array_equal(ev[hitm], ref["steps_s"][sl].reshape(-1)[hitm]), "shadow step counts differ from the oracle's"
+            tot[2:4] += [ss, ks]; tot[5] += ps
+print("sample of %d tiles: primary wave steps %d, pair skipped in %.1f %%; shadow wave steps %d, pair skipped in %.1f %%" %
+      (len(range(0, th, stride)) * len(range(0, tw, stride)), tot[0], 100 * tot[1] / tot[0], tot[2], 100 * tot[3] / max(tot[2], 1)))
+print("decided before the evaluation (bounds of both halves): primary %.1f %%, shadow %.1f %%" % (100 * tot[4] / tot[0], 100 * tot[5] / max(tot[2], 1)))

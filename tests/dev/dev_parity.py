@@ -1,5 +1,5 @@
 import sys, time
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from raymarching_amd import Material, Raymarching, RenderTexture, scenes
 from oracle import rm_oracle as O

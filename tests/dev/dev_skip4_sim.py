@@ -1,8 +1,8 @@
-"""CPU simulation (developer tool):   python scripts/dev_skip4_sim.py W H N_TILES
+"""CPU simulation (developer tool):   python tests/dev/dev_skip4_sim.py W H N_TILES
 How often could the 4-slot scene's march skip (sphere, box), the sphere alone or the link, exactly, from bounds carried
 from the last values each primitive was evaluated at (every leaf is 1-Lipschitz)?  Wave-uniform votes over 8x8 tiles."""
 import sys, os, math
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 from oracle import numpy_restatement as R, rm_oracle as O

@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import numpy_restatement as R            # noqa: E402
 from raymarching_amd import scenes                    # noqa: E402
 from tests import cases                                # noqa: E402

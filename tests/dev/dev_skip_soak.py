@@ -1,12 +1,12 @@
 """Developer tool: a long run of seeded random tables (tests/cases.py::random_table_case, with and without op bits, at
 several world scales) through the automatic kernel choice, each frame compared bit for bit with the CPU oracle.
 
-    python scripts/dev_skip_soak.py FIRST_SEED N_SEEDS
+    python tests/dev/dev_skip_soak.py FIRST_SEED N_SEEDS
 """
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np                      # noqa: E402

@@ -143,13 +143,15 @@ def _worker(rank, world, port, out_dir):
             t = tg.submit(frames, hits)
             counts = tg.complete(t, on_received)
             tg.drain()
-            assert len(counts) == world and all(0 < c < len(mine) * tiles for c in counts)
+            assert len(counts) == world and 0 < counts[rank] < len(mine) * tiles
             if rank == 0:
+                assert all(0 < c < len(mine) * tiles for c in counts)         # the root is told every count, a peer only knows its own
                 assert sorted(delivered) == list(range(n_poses))
                 for k in range(n_poses):
                     ref = O.render(O.Uniforms(pose_props(k)), w, h, threads=2)["rgba"]
                     assert np.array_equal(delivered[k], ref), f"pose {k} differs after the compact gather"
             else:
+                assert all(c == -1 for i, c in enumerate(counts) if i != rank)
                 assert not delivered and tg.bytes_sent == (rep + 1) * counts[rank] * RECORD_WORDS * 4
         # ---- the root keeps its dense frames: later deliveries into a slot update the tiles that changed ----------
         from helpers import update_frames_numpy
