@@ -8,6 +8,11 @@
 // lerp(a,b,t) = a + t*(b-a), min/max drop NaN operands.  All arithmetic is float: each
 // product and sum is cast back to float so that a JIT working in double cannot keep excess
 // precision.  "cginc" = Assets/Raymarching.cginc, "shader" = Assets/Raymarching.shader.
+//
+// Covered: the 4-slot scene of the three matrices, N-primitive tables (five primitive types, smax / negation bits, the
+// level-wise pairwise tree), _MainTex and the depth texture as inputs, the shadow-map lookup in both modes, the two depth
+// passes, per-pixel step counts.  Not covered (C oracle only): the fractal / terrain bodies, the domain operators and
+// frag's optional lines.
 using System;
 using System.Threading.Tasks;
 
@@ -24,6 +29,22 @@ public static class RaymarchingOracle
         public float MaxSteps = 400, MaxDist = 50, StepFactor = 0.7f, ContactThreshold = 0.002f, NormalSampleScale = 0.00005f;
         public float FarPlane = 1000;
         public F3 Background = new F3(0.19215687f, 0.3019608f, 0.4745098f);
+        public float SmoothK = 0.5f;
+        public Primitive[] Table;                 // null: the 4-slot scene of Positions / Rotations / Scales
+        // shadow-map lookup in place of the shadow march (0 off, 1 perspective map through ShadowVP, 2 directional map)
+        public int ShadowMode;
+        public float[] ShadowVP = new float[16];  // projection * worldToCamera of the shadow camera, column-major
+        public float[] ShadowCorners = new float[12]; public F3 ShadowForward;     // rectangle TL, TR, BR, BL and its forward
+        public float[] ShadowMap; public int ShadowW, ShadowH; public float ShadowBias = 0.01f;
+    }
+
+    public const int Sphere_ = 0, Box_ = 1, Link_ = 2, Cylinder_ = 3, Torus_ = 4, OpSmax = 1, OpNegate = 2;
+    // one row of a primitive table: the fields of RmHip.Primitive
+    public struct Primitive
+    {
+        public int type, op;
+        public F3 pos; public F4 quat; public F3 scale, color;
+        public float p0, p1, p2, p3;
     }
 
     static float Mul(float a, float b) { return (float)(a * b); }
@@ -54,12 +75,13 @@ public static class RaymarchingOracle
         var c = new F3(Sub(Mul(u.y, v.z), Mul(u.z, v.y)), Sub(Mul(u.z, v.x), Mul(u.x, v.z)), Sub(Mul(u.x, v.y), Mul(u.y, v.x)));
         return AddV(AddV(t1, t2), Scale(c, Mul(2f, q.w)));
     }
-    static float Sphere(F3 p) { return Sub(Len(p), 0.5f); }                                            // cginc:169-171, r = 1
-    static float Box(F3 p)                                                                              // cginc:173-177, b = 1
+    static float Sphere(F3 p, float r) { return Sub(Len(p), Mul(r, 0.5f)); }                            // cginc:169-171
+    static float Box(F3 p, F3 b)                                                                        // cginc:173-177
     {
-        float dx = Sub(Math.Abs(p.x), 0.5f), dy = Sub(Math.Abs(p.y), 0.5f), dz = Sub(Math.Abs(p.z), 0.5f);
+        float dx = Sub(Math.Abs(p.x), Mul(b.x, 0.5f)), dy = Sub(Math.Abs(p.y), Mul(b.y, 0.5f)), dz = Sub(Math.Abs(p.z), Mul(b.z, 0.5f));
         return Add(Len(new F3(Max(dx, 0f), Max(dy, 0f), Max(dz, 0f))), Min(Max(dx, Max(dy, dz)), 0f));
     }
+    static float Torus(F3 p, float tx, float ty) { return Sub(Len2(Sub(Len2(p.x, p.y), tx), p.z), ty); } // cginc:179-182
     static float Link(F3 p, float le, float r1, float r2)                                               // cginc:184-187
     {
         float qy = Max(Sub(Math.Abs(p.y), le), 0f);
@@ -77,32 +99,77 @@ public static class RaymarchingOracle
         F3 col = Scale(Normalize(Lerp(c1, c2, h)), Lerp(Len(c1), Len(c2), h));
         return new F4(col.x, col.y, col.z, Sub(Lerp(b.w, a.w, h), Mul(Mul(k, h), Sub(1f, h))));
     }
-    // cginc:334-364
-    static F4 Scene(Uniforms u, F3 p)
+    // cginc:120-123: plain lerp of rgb, and the reference's sign of the k*h*(1-h) term
+    static F4 Smax(F4 a, F4 b, float k)
     {
-        var o = new F4[4];
+        float h = Clamp(Add(0.5f, Div(Mul(0.5f, Sub(a.w, b.w)), k)), 0f, 1f);
+        F3 col = Lerp(new F3(b.x, b.y, b.z), new F3(a.x, a.y, a.z), h);
+        return new F4(col.x, col.y, col.z, Sub(-Lerp(-b.w, -a.w, h), Mul(Mul(k, h), Sub(1f, h))));
+    }
+    // the 4-slot scene as a table: sphere, box, link(5,5,.1), cylinder(.5,.5) with the colours of cginc:351-359
+    static Primitive[] LegacyTable(Uniforms u)
+    {
         var col = new[] { new F3(1, .25f, .25f), new F3(.25f, 1, .25f), new F3(.25f, .25f, 1), new F3(1, 1, .25f) };
+        var par = new[] { new F4(1, 0, 0, 0), new F4(1, 1, 1, 0), new F4(5, 5, .1f, 0), new F4(.5f, .5f, 0, 0) };
+        var t = new Primitive[4];
         for (int i = 0; i < 4; i++)
         {
             F4 P = Row(u.Positions, i), S = Row(u.Scales, i);
-            F3 l = Rotate(SubV(p, new F3(P.x, P.y, P.z)), Row(u.Rotations, i));
-            l = new F3(Div(l.x, S.x), Div(l.y, S.y), Div(l.z, S.z));
-            float d = i == 0 ? Sphere(l) : i == 1 ? Box(l) : i == 2 ? Link(l, 5f, 5f, .1f) : Cylinder(l, .5f, .5f);
-            o[i] = new F4(col[i].x, col[i].y, col[i].z, Mul(d, Min(S.x, Min(S.y, S.z))));
+            t[i] = new Primitive { type = i, op = 0, pos = new F3(P.x, P.y, P.z), quat = Row(u.Rotations, i), scale = new F3(S.x, S.y, S.z),
+                                   color = col[i], p0 = par[i].x, p1 = par[i].y, p2 = par[i].z, p3 = par[i].w };
         }
-        return Smin(Smin(o[0], o[1], .5f), Smin(o[2], o[3], .5f), .5f);
+        return t;
+    }
+    // the wrapper of cginc:336-354 around one primitive: prim(rotate(p - pos, q) / scale) * min(scale), negated on request
+    static float PrimDist(Primitive pr, F3 p)
+    {
+        F3 l = Rotate(SubV(p, pr.pos), pr.quat);
+        l = new F3(Div(l.x, pr.scale.x), Div(l.y, pr.scale.y), Div(l.z, pr.scale.z));
+        float d;
+        switch (pr.type)
+        {
+            case Sphere_: d = Sphere(l, pr.p0); break;
+            case Box_: d = Box(l, new F3(pr.p0, pr.p1, pr.p2)); break;
+            case Link_: d = Link(l, pr.p0, pr.p1, pr.p2); break;
+            case Cylinder_: d = Cylinder(l, pr.p0, pr.p1); break;
+            default: d = Torus(l, pr.p0, pr.p1); break;
+        }
+        d = Mul(d, Min(pr.scale.x, Min(pr.scale.y, pr.scale.z)));
+        return (pr.op & OpNegate) != 0 ? -d : d;
+    }
+    // cginc:334-364.  Four primitives: smin(smin(o0,o1), smin(o2,o3)) (cginc:363).  Any other count: the same pairwise tree,
+    // level by level in index order, an odd element at the end of a level carried up unchanged; the op bits of the first leaf
+    // of a node's right operand choose smax for that node.
+    static F4 Scene(Uniforms u, Primitive[] t, F3 p)
+    {
+        int n = t.Length;
+        var o = new F4[n]; var first = new int[n];
+        for (int i = 0; i < n; i++) { o[i] = new F4(t[i].color.x, t[i].color.y, t[i].color.z, PrimDist(t[i], p)); first[i] = i; }
+        while (n > 1)
+        {
+            int m = 0;
+            for (int i = 0; i + 1 < n; i += 2)
+            {
+                bool smax = (t[first[i + 1]].op & OpSmax) != 0;
+                first[m] = first[i];
+                o[m++] = smax ? Smax(o[i], o[i + 1], u.SmoothK) : Smin(o[i], o[i + 1], u.SmoothK);
+            }
+            if ((n & 1) != 0) { first[m] = first[n - 1]; o[m++] = o[n - 1]; }
+            n = m;
+        }
+        return o[0];
     }
 
     struct March { public bool hit; public int evals; public float length, contact; }
     // cginc:367-392
-    static March Raymarch(Uniforms u, F3 ro, F3 rd, float depth)
+    static March Raymarch(Uniforms u, Primitive[] t, F3 ro, F3 rd, float depth)
     {
         depth = Min(depth, u.MaxDist);
         float steps = Min(2000f, u.MaxSteps), dm = 0f;
         var r = new March { contact = u.ContactThreshold };
         for (int i = 0; (float)i < steps; i++)
         {
-            float dts = Scene(u, AddV(ro, Scale(rd, dm))).w;
+            float dts = Scene(u, t, AddV(ro, Scale(rd, dm))).w;
             r.evals++;
             dm = Add(dm, Mul(Math.Abs(dts), u.StepFactor));
             r.contact = Mul(dm, .0025f);
@@ -113,14 +180,14 @@ public static class RaymarchingOracle
         return r;
     }
     // shader:102-123
-    static float Shadow(Uniforms u, F3 p, F3 n, float contact, out int evals)
+    static float Shadow(Uniforms u, Primitive[] t, F3 p, F3 n, float contact, out int evals)
     {
         float depth = Min(2000f, u.MaxDist), steps = Min(2000f, u.MaxSteps), dm = 0f, res = 1f;
         p = AddV(p, Scale(Scale(n, contact), 2f));
         evals = 0;
         for (int i = 0; (float)i < steps; i++)
         {
-            float dts = Scene(u, AddV(p, Scale(u.Light, dm))).w;
+            float dts = Scene(u, t, AddV(p, Scale(u.Light, dm))).w;
             evals++;
             res = Min(res, Div(Mul(16f, dts), dm));
             dm = Add(dm, Mul(Math.Abs(dts), u.StepFactor));
@@ -130,10 +197,42 @@ public static class RaymarchingOracle
         }
         return res;
     }
+    // Shadow-map lookup in place of the shadow march (this library's definition; the reference declares _ShadowMap and
+    // _ShadowMapVPMatrix at shader:45-46 and never reads them): 1 = lit, 0 = in shadow; lit outside the map.
+    static float ShadowLookup(Uniforms u, F3 p, F3 n, float contact)
+    {
+        F3 q = AddV(p, Scale(Scale(n, contact), 2f));                                                 // shader:107
+        float uu, vv, d;
+        if (u.ShadowMode == 1)
+        {
+            F4 r0 = Row(u.ShadowVP, 0), r1 = Row(u.ShadowVP, 1), r3 = Row(u.ShadowVP, 3);
+            float cx = Add(Add(Add(Mul(r0.x, q.x), Mul(r0.y, q.y)), Mul(r0.z, q.z)), r0.w);
+            float cy = Add(Add(Add(Mul(r1.x, q.x), Mul(r1.y, q.y)), Mul(r1.z, q.z)), r1.w);
+            float cw = Add(Add(Add(Mul(r3.x, q.x), Mul(r3.y, q.y)), Mul(r3.z, q.z)), r3.w);
+            if (!(cw > 0f)) return 1f;
+            uu = Add(Mul(Div(cx, cw), .5f), .5f);
+            vv = Add(Mul(Div(cy, cw), .5f), .5f);
+            d = cw;
+        }
+        else
+        {
+            float[] k = u.ShadowCorners;
+            var bl = new F3(k[9], k[10], k[11]);
+            F3 e1 = SubV(new F3(k[6], k[7], k[8]), bl), e2 = SubV(new F3(k[0], k[1], k[2]), bl), r = SubV(q, bl);
+            uu = Div(Dot(r, e1), Dot(e1, e1));
+            vv = Div(Dot(r, e2), Dot(e2, e2));
+            d = Dot(r, u.ShadowForward);
+        }
+        if (!(uu >= 0f && uu < 1f && vv >= 0f && vv < 1f)) return 1f;
+        int ix = (int)Math.Floor(Mul(uu, u.ShadowW)), iy = (int)Math.Floor(Mul(vv, u.ShadowH));
+        if (ix > u.ShadowW - 1) ix = u.ShadowW - 1;
+        if (iy > u.ShadowH - 1) iy = u.ShadowH - 1;
+        float stored = u.ShadowMap[(long)iy * u.ShadowW + ix];
+        return d > Mul(stored, Add(1f, u.ShadowBias)) ? 0f : 1f;
+    }
     static byte Unorm8(float x) { x = Min(Max(x, 0f), 1f); return (byte)Math.Floor(Add(Mul(x, 255f), 0.5f)); }
 
-    // shader:149-216 for every pixel; row 0 = bottom row.  Returns hit count.
-    public static long Render(Uniforms u, int w, int h, byte[] rgba, float[] depthOut, byte[] hitOut)
+    static F3[] WorldCorners(Uniforms u)
     {
         F3[] c = new F3[4];
         for (int i = 0; i < 4; i++)
@@ -142,37 +241,83 @@ public static class RaymarchingOracle
             F4 r0 = Row(u.CamInvView, 0), r1 = Row(u.CamInvView, 1), r2 = Row(u.CamInvView, 2);
             c[i] = new F3(Dot(new F3(r0.x, r0.y, r0.z), v3), Dot(new F3(r1.x, r1.y, r1.z), v3), Dot(new F3(r2.x, r2.y, r2.z), v3));
         }
+        return c;
+    }
+
+    // shader:149-216 for every pixel; row 0 = bottom row.  src (RGBA8, may be null: Background) is _MainTex, sceneDepth (may be
+    // null: FarPlane) the depth texture as linear eye depth (shader:154); steps (may be null) receives the evaluations of the
+    // primary and of the shadow march per pixel.  Returns the hit count.
+    public static long Render(Uniforms u, int w, int h, byte[] src, float[] sceneDepth, byte[] rgba, float[] depthOut, byte[] hitOut,
+                              ushort[] steps = null)
+    {
+        F3[] c = WorldCorners(u);
+        Primitive[] t = u.Table ?? LegacyTable(u);
         long hits = 0;
         Parallel.For(0, h, () => 0L, (y, _, local) =>
         {
             for (int x = 0; x < w; x++)
             {
+                int idx = y * w + x;
                 float uu = Div(Add(x, 0.5f), w), vv = Div(Add(y, 0.5f), h);
                 F3 rd = Lerp(Lerp(c[3], c[2], uu), Lerp(c[0], c[1], uu), vv);
-                March r = Raymarch(u, u.CamPos, rd, u.FarPlane);
-                F3 col = u.Background;
+                March r = Raymarch(u, t, u.CamPos, rd, sceneDepth != null ? sceneDepth[idx] : u.FarPlane);
+                F3 col = src != null ? new F3(Div(src[4 * idx], 255f), Div(src[4 * idx + 1], 255f), Div(src[4 * idx + 2], 255f)) : u.Background;
+                int ev = 0;
                 if (r.hit)
                 {
                     F3 hp = AddV(u.CamPos, Scale(rd, r.length));
                     float e = Max(0f, u.NormalSampleScale);
                     var raw = new F3(
-                        Sub(Scene(u, new F3(Add(hp.x, e), hp.y, hp.z)).w, Scene(u, new F3(Sub(hp.x, e), hp.y, hp.z)).w),
-                        Sub(Scene(u, new F3(hp.x, Add(hp.y, e), hp.z)).w, Scene(u, new F3(hp.x, Sub(hp.y, e), hp.z)).w),
-                        Sub(Scene(u, new F3(hp.x, hp.y, Add(hp.z, e))).w, Scene(u, new F3(hp.x, hp.y, Sub(hp.z, e))).w));
+                        Sub(Scene(u, t, new F3(Add(hp.x, e), hp.y, hp.z)).w, Scene(u, t, new F3(Sub(hp.x, e), hp.y, hp.z)).w),
+                        Sub(Scene(u, t, new F3(hp.x, Add(hp.y, e), hp.z)).w, Scene(u, t, new F3(hp.x, Sub(hp.y, e), hp.z)).w),
+                        Sub(Scene(u, t, new F3(hp.x, hp.y, Add(hp.z, e))).w, Scene(u, t, new F3(hp.x, hp.y, Sub(hp.z, e))).w));
                     F3 n = Normalize(raw);
-                    F4 s = Scene(u, hp);
-                    int ev;
-                    float shadow = Add(Mul(Div(Sub(Shadow(u, hp, n, r.contact, out ev), 0f), Sub(1f, 0f)), Sub(1f, .25f)), .25f);
+                    F4 s = Scene(u, t, hp);
+                    float sh = u.ShadowMode != 0 ? ShadowLookup(u, hp, n, r.contact) : Shadow(u, t, hp, n, r.contact, out ev);
+                    float shadow = Add(Mul(Div(Sub(sh, 0f), Sub(1f, 0f)), Sub(1f, .25f)), .25f);                    // remap, cginc:80-82
                     float ndl = Add(Mul(Dot(n, u.Light), .5f), .5f);
                     float nss = u.NormalSampleScale;
                     float ao = Clamp(Len(new F3(Div(raw.x, nss), Div(raw.y, nss), Div(raw.z, nss))), 0f, 1f);
                     col = Scale(Scale(Scale(new F3(s.x, s.y, s.z), ndl), shadow), ao);
                     local++;
                 }
+                if (rgba != null) { rgba[4 * idx] = Unorm8(col.x); rgba[4 * idx + 1] = Unorm8(col.y); rgba[4 * idx + 2] = Unorm8(col.z); rgba[4 * idx + 3] = 255; }
+                if (depthOut != null) depthOut[idx] = r.length;
+                if (hitOut != null) hitOut[idx] = (byte)(r.hit ? 1 : 0);
+                if (steps != null) { steps[2 * idx] = (ushort)r.evals; steps[2 * idx + 1] = (ushort)(r.hit ? ev : 0); }
+            }
+            return local;
+        }, local => System.Threading.Interlocked.Add(ref hits, local));
+        return hits;
+    }
+
+    // The depth passes (this library's definition: the reference's ShadowMap fragment is a stub): raymarch() from the shadow
+    // camera through the pixel's ray (corners12 == null; ShadowMap.cs Render) or orthographically from the rectangle of
+    // ShadowMapDirectional.cs:25-34 (corners TL, TR, BR, BL as 12 floats) along forward.  Writes r.length; returns the hit count.
+    public static long RenderDepth(Uniforms u, int w, int h, float[] corners12, F3 forward, float[] depthOut, byte[] hitOut)
+    {
+        F3[] c = WorldCorners(u);
+        Primitive[] t = u.Table ?? LegacyTable(u);
+        F3[] dc = null;
+        if (corners12 != null)
+        {
+            dc = new F3[4];
+            for (int i = 0; i < 4; i++) dc[i] = new F3(corners12[3 * i], corners12[3 * i + 1], corners12[3 * i + 2]);
+        }
+        long hits = 0;
+        Parallel.For(0, h, () => 0L, (y, _, local) =>
+        {
+            for (int x = 0; x < w; x++)
+            {
+                float uu = Div(Add(x, 0.5f), w), vv = Div(Add(y, 0.5f), h);
+                F3 ro = u.CamPos, rd;
+                if (dc == null) rd = Lerp(Lerp(c[3], c[2], uu), Lerp(c[0], c[1], uu), vv);
+                else { ro = Lerp(Lerp(dc[3], dc[2], uu), Lerp(dc[0], dc[1], uu), vv); rd = forward; }
+                March r = Raymarch(u, t, ro, rd, u.FarPlane);
                 int idx = y * w + x;
-                rgba[4 * idx] = Unorm8(col.x); rgba[4 * idx + 1] = Unorm8(col.y); rgba[4 * idx + 2] = Unorm8(col.z); rgba[4 * idx + 3] = 255;
-                depthOut[idx] = r.length;
-                hitOut[idx] = (byte)(r.hit ? 1 : 0);
+                if (depthOut != null) depthOut[idx] = r.length;
+                if (hitOut != null) hitOut[idx] = (byte)(r.hit ? 1 : 0);
+                if (r.hit) local++;
             }
             return local;
         }, local => System.Threading.Interlocked.Add(ref hits, local));
