@@ -291,7 +291,8 @@ int rm_debug_counter_slots(rm_ctx *ctx, uint32_t *out, int max_words, int *words
  * kernels whose frames are bit-identical: 1 one wave per 8x8 tile, 2 persistent tile queue, 3 persistent waves with lane
  * refill, 5 four waves per tile that split the primitive table (tables of 3 to 512 primitives; others take 1; tables of 33 to 512
  * primitives, from 65 with op bits, also skip the subtrees that cannot change a bit of a march step's result, unless the
- * float property _RmTableSkip is 0).  4 = the
+ * float property _RmTableSkip is 0; likewise the soft-shadow march of the unrotated 4-slot scene skips the sphere and the box
+ * while they provably cannot change a bit of the step's result, unless the float property _RmPairSkip is 0).  4 = the
  * opt-in tolerance kernel for the reference's 4-slot scene (fused multiply-adds and hardware sqrt/rcp in the two march
  * loops): frames within the port's tolerance, not bit-identical; every other scene is rendered by the exact kernels. */
 int rm_set_kernel(rm_ctx *ctx, int variant);

@@ -441,6 +441,46 @@ SKIP_CASES = [
 BY_NAME.update({c.name: c for c in SKIP_CASES})
 
 
+def _scaled_unrotated(scl, floats=None, vectors=None, quats=None):
+    """the four slots with non-unit scales and no rotation: the kernel variants whose soft-shadow march skips the (sphere, box)
+    pair while it provably cannot change a bit of the step's result"""
+    def f(case, mat):
+        ts = scenes.default_transforms()
+        for i, (t, s_) in enumerate(zip(ts, scl)):
+            t.lossyScale = np.asarray(s_, dtype=F)
+            if quats is not None:
+                t.rotation = np.asarray(quats[i], dtype=F)
+        _base(mat, case.w, case.h, transforms=ts)
+        for k, v in (floats or {}).items():
+            mat.SetFloat(k, v)
+        for k, v in (vectors or {}).items():
+            mat.SetVector(k, np.asarray(v, dtype=F))
+    return f
+
+
+_ANISO = [(1.3, 0.8, 1.1), (0.7, 1.9, 1.2), (0.9, 1.1, 1.05), (1.6, 0.6, 1.0)]
+# The pair skip of the 4-slot soft-shadow march: scales of the reciprocal, power-of-two and true-division variants, lights that
+# make long shadow marches, and the guards (a negative scale, a zero scale, an infinite scale, a quaternion that is not of unit
+# length: the skip must then stay off and the frame still be the oracle's).  Compared with the oracle on the GPU only.
+PAIR_SKIP_CASES = [
+    Case("pair_skip_scaled_400x225", 400, 225, setup=_scaled_unrotated(_ANISO)),
+    Case("pair_skip_pow2_320x180", 320, 180, setup=_scaled_unrotated([(2.0, 1.0, 0.5), (0.5, 2.0, 1.0), (1.0, 1.0, 1.0), (2.0, 0.5, 1.0)])),
+    Case("pair_skip_truediv_320x180", 320, 180,
+         setup=_scaled_unrotated([(1.3, float(np.float32(1.9999999)), 1.1), (0.7, 1.9, 1.2), (0.9, 1.1, 1.05), (1.6, 0.6, 1.0)])),
+    Case("pair_skip_low_light_320x180", 320, 180, setup=_scaled_unrotated(_ANISO, vectors={"_WorldSpaceLightPos0": (0.9, 0.12, -0.4, 0)})),
+    Case("pair_skip_unit_low_light_480x270", 480, 270, setup=_edge(vectors={"_WorldSpaceLightPos0": (-0.8, 0.1, 0.55, 0)})),
+    Case("pair_skip_long_light_vector_320x180", 320, 180, setup=_edge(vectors={"_WorldSpaceLightPos0": (1.4, 2.5, -1.9, 0)})),
+    Case("pair_skip_small_steps_240x135", 240, 135, setup=_scaled_unrotated(_ANISO, floats={"_StepFactor": 0.2, "_MaxSteps": 900.0})),
+    Case("pair_skip_big_scene_240x135", 240, 135, setup=_scaled_unrotated([(4.0, 4.0, 4.0), (3.0, 5.0, 2.0), (1.0, 1.0, 1.0), (6.0, 0.5, 6.0)])),
+    Case("pair_skip_negative_scale_200x112", 200, 112, setup=_scaled_unrotated([(1.3, -0.8, 1.1), (0.7, 1.9, 1.2), (0.9, 1.1, 1.05), (1.6, 0.6, 1.0)])),
+    Case("pair_skip_zero_scale_200x112", 200, 112, setup=_scaled_unrotated([(1.3, 0.8, 1.1), (0.7, 0.0, 1.2), (0.9, 1.1, 1.05), (1.6, 0.6, 1.0)])),
+    Case("pair_skip_inf_scale_200x112", 200, 112, setup=_scaled_unrotated([(float("inf"), 0.8, 1.1), (0.7, 1.9, 1.2), (0.9, 1.1, 1.05), (1.6, 0.6, 1.0)])),
+    Case("pair_skip_long_quaternion_200x112", 200, 112,
+         setup=_scaled_unrotated(_ANISO, quats=[(0.0, 0.0, 0.0, 1.5), (0.0, 0.0, 0.0, 1.0), (0.0, 0.0, 0.0, 1.0), (0.0, 0.0, 0.0, 1.0)])),
+]
+BY_NAME.update({c.name: c for c in PAIR_SKIP_CASES})
+
+
 def oracle_run(case: Case, O, threads: int = 0) -> dict:
     """binds the case on a fresh material and renders it with the CPU oracle"""
     with Material() as mat:

@@ -168,6 +168,22 @@ def test_exact_culling_in_table_marches_equals_oracle(oracle, torch_cuda, name):
         assert g["stats"]["sum_steps_p"] == ref["stats"]["sum_steps_p"]
 
 
+@pytest.mark.parametrize("name", [c.name for c in cases.PAIR_SKIP_CASES])
+def test_pair_skip_in_the_shadow_march_equals_oracle(oracle, torch_cuda, name):
+    """4-slot scenes without rotation: the soft-shadow march leaves out the (sphere, box) pair while its lower bound stays .5
+    above the right pair's value; frames and counters are the oracle's on every exact kernel, and the same with the skip
+    switched off (_RmPairSkip 0)"""
+    case = cases.BY_NAME[name]
+    ref = cases.oracle_run(case, oracle)
+    runs = [gpu_run(case, torch_cuda, kernel=k) for k in (0, KERNELS["tile"], KERNELS["queue"], KERNELS["stream"])]
+    runs.append(gpu_run(case, torch_cuda, floats={"_RmPairSkip": 0.0}))
+    for g in runs:
+        assert_frame_equal(g, ref, name)
+        assert g["stats"]["sum_steps_s"] == ref["stats"]["sum_steps_s"]
+        assert g["stats"]["sum_steps_p"] == ref["stats"]["sum_steps_p"]
+        assert g["stats"]["n_hit"] == int(ref["hit"].sum())
+
+
 @pytest.mark.parametrize("kernel,frames", [("tile", 1), ("queue", 1), ("queue", 4), ("stream", 2)])
 @pytest.mark.parametrize("name", ["default_1920x1080", "default_3840x2160"])
 def test_gpu_full_size_matches_golden_hashes(torch_cuda, name, kernel, frames):
