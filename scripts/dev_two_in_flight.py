@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Renders the default 1080p frame N times from one context on one stream, then 2N times from two contexts on two
+"""Renders the default frame (1080p, or the size given after N) N times from one context on one stream, then 2N times from two contexts on two
 streams (frames_in_flight 2).  Meant to run under `rocprofv3 --kernel-trace`: scripts/summarise_overlap.py reads the
 dispatch intervals of the two phases from the trace.  Prints the wall-clock per frame of both phases."""
 import json
@@ -16,7 +16,7 @@ from raymarching_amd.material import _ptr  # noqa: E402
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    w, h = 1920, 1080
+    w, h = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
     dev = "cuda:0"
     torch.cuda.set_device(0)
     mats, frames = [], []

@@ -58,7 +58,7 @@ def main():
         except Exception as e:
             lines.append(f"(code-object metadata not read: {e})")
     counters = {}
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_grbm", "pmc_sq2", "pmc_tcp", "pmc_lds"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_grbm", "pmc_sq2", "pmc_tcp", "pmc_lds", "pmc_ops"):
         db = os.path.join(src, sub, "bench_results.db")
         if not os.path.exists(db):
             continue
