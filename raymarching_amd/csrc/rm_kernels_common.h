@@ -73,12 +73,15 @@ RM_DI MarchResult rm_raymarch(const S &sc, V3 ro, V3 rd, float depth, int n_step
 // right operand b, h is 0 and the value is (b - (-0)) - 0 = b + 0, whatever a is.  Every primitive is a Euclidean distance
 // function times min(scale) of a point divided by scale, so with positive scales it -- and any smin of such -- changes by at most
 // the distance the sample point moves.  The march therefore keeps a lower bound of the left pair: its last evaluated value less
-// |L| times the march distance covered since.  While that bound stays .51 (+ 1e-4 of its magnitude: the rounding of the bound
-// and of the evaluations, for coordinates of any size) above the right pair's value in EVERY lane of the wave still marching,
-// the left pair (sphere, box: 46 of the ~100 instructions of an evaluation) is not evaluated.  Shadow rays that slide along
-// the link or the cylinder -- the longest dependent chains of a frame of the sample scene -- run on the right pair alone;
-// on a sample of 2040 tiles of the 1080p frame 59 % of the shadow wave steps skip (primary marches: 14 %, which does not
-// pay for the vote there), with every distance, step count and depth bit unchanged (tests/dev/dev_pair_skip_sim.py).
+// |L| times the march distance covered since, less 2^-21 of the largest coordinate the march can reach per step (the sample
+// points are fp32 sums: a point may move an ulp further than the march distance says).  While that bound stays .51 (+ 1e-4 of
+// its magnitude: the rounding of the bound and of the evaluations) above the right pair's value in EVERY lane of the wave
+// still marching, the left pair (sphere, box: 46 of the ~100 instructions of an evaluation) is not evaluated.  Marches that
+// can reach coordinates beyond 1000 never skip (the .01 of slack is sized for evaluation errors below that).  Shadow rays
+// that slide along the link or the cylinder -- the longest dependent chains of a frame of the sample scene -- run on the
+// right pair alone; on samples of the 1080p frame's tiles between a fifth and three fifths of the shadow wave steps skip
+// (primary marches: 12-15 %, which does not pay for the vote there), with every distance, step count and depth bit unchanged
+// (tests/dev/dev_pair_skip_sim.py).
 template <class S>
 RM_DI float rm_getshadow(const S &sc, V3 p, V3 n, V3 L, float contact, float depth, int n_steps, float sf, int &evals) {
     const float kc = rm_vgpr(.0025f);
@@ -88,7 +91,10 @@ RM_DI float rm_getshadow(const S &sc, V3 p, V3 n, V3 L, float contact, float dep
     constexpr bool FAST = rm_is_fast<S>::value;
     if constexpr (rm_pair_skip<S>::value && !FAST) {
         const bool may_skip = sc.lipschitz();
-        const float len = sqrtf(rm_dot3(L, L)) * 1.0011f;        // the sample point moves by at most len * (step in dm); the host admits quaternions up to |q|^2 = 1.001
+        const float len0 = sqrtf(rm_dot3(L, L)) * 1.0011f;       // the sample point moves by at most len0 * (step in dm); the host admits quaternions up to |q|^2 = 1.001
+        const float cmax = fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fabsf(p.z)) + len0 * depth;     // no coordinate of a sample point exceeds this
+        const float len = cmax < 1000.0f ? len0 : __builtin_inff();                             // (NaN included: the bound then never holds)
+        const float eps = cmax * 4.76837158203125e-07f;          // 2^-21 of it: four ulps
         float lb = -__builtin_inff();                            // lower bound of left(cp); -inf: unknown
         for (int i = 0; i < n_steps; i++) {
             const V3 cp = mk3(p.x + L.x * dm, p.y + L.y * dm, p.z + L.z * dm);
@@ -105,7 +111,7 @@ RM_DI float rm_getshadow(const S &sc, V3 p, V3 n, V3 L, float contact, float dep
             res = fminf(res, 16.0f * dts / dm);
             const float inc = fabsf(dts) * sf;
             dm = dm + inc;
-            lb = lb - inc * len;
+            lb = (lb - inc * len) - eps;
             contact = dm * kc;
             if (fabsf(dts) < contact) break;
             if (dm > depth) break;

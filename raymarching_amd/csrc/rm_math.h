@@ -264,10 +264,11 @@ struct Scene4Plain : Scene4<ROT, SCL> {
 };
 template <bool ROT, int SCL, int SHAPE> struct rm_shape<Scene4Plain<ROT, SCL, SHAPE>> { static constexpr int value = SHAPE; };
 // (scenes without per-primitive rotation only: the rotated variants already fill their 256 registers, and the second copy of
-// the right pair's code that the skipping loop needs made them spill inside the march)
+// the right pair's code that the skipping loop needs made them spill inside the march; the reciprocal-exact scale variant,
+// compiled for three waves per SIMD, spilled 32 bytes with it and gained nothing)
 #ifndef RM_NO_PAIR_SKIP
-template <int SCL> struct rm_pair_skip<Scene4<false, SCL>> { static constexpr bool value = true; };
-template <int SCL, int SHAPE> struct rm_pair_skip<Scene4Plain<false, SCL, SHAPE>> { static constexpr bool value = true; };
+template <int SCL> struct rm_pair_skip<Scene4<false, SCL>> { static constexpr bool value = SCL != RM_SCL_RCP; };
+template <int SCL, int SHAPE> struct rm_pair_skip<Scene4Plain<false, SCL, SHAPE>> { static constexpr bool value = SCL != RM_SCL_RCP; };
 #endif
 
 // N-primitive scene from a table in global memory.  Every lane walks the table

@@ -458,6 +458,21 @@ def _scaled_unrotated(scl, floats=None, vectors=None, quats=None):
     return f
 
 
+def _offset_scene(offset, scl=None):
+    """the 4-slot scene and its camera moved away from the origin: sample points with large coordinates (coarse ulps)"""
+    def f(case, mat):
+        off = np.asarray(offset, dtype=F)
+        ts = scenes.default_transforms()
+        for i, t in enumerate(ts):
+            t.position = (np.asarray(t.position, dtype=F) + off).astype(F)
+            if scl is not None:
+                t.lossyScale = np.asarray(scl[i], dtype=F)
+        cam = scenes.default_camera(case.w, case.h)
+        cam.transform.position = (np.asarray(cam.transform.position, dtype=F) + off).astype(F)
+        _base(mat, case.w, case.h, camera=cam, transforms=ts)
+    return f
+
+
 _ANISO = [(1.3, 0.8, 1.1), (0.7, 1.9, 1.2), (0.9, 1.1, 1.05), (1.6, 0.6, 1.0)]
 # The pair skip of the 4-slot soft-shadow march: scales of the reciprocal, power-of-two and true-division variants, lights that
 # make long shadow marches, and the guards (a negative scale, a zero scale, an infinite scale, a quaternion that is not of unit
@@ -472,6 +487,10 @@ PAIR_SKIP_CASES = [
     Case("pair_skip_long_light_vector_320x180", 320, 180, setup=_edge(vectors={"_WorldSpaceLightPos0": (1.4, 2.5, -1.9, 0)})),
     Case("pair_skip_small_steps_240x135", 240, 135, setup=_scaled_unrotated(_ANISO, floats={"_StepFactor": 0.2, "_MaxSteps": 900.0})),
     Case("pair_skip_big_scene_240x135", 240, 135, setup=_scaled_unrotated([(4.0, 4.0, 4.0), (3.0, 5.0, 2.0), (1.0, 1.0, 1.0), (6.0, 0.5, 6.0)])),
+    Case("pair_skip_offset_600_320x180", 320, 180, setup=_offset_scene((600.0, -300.0, 450.0))),
+    Case("pair_skip_offset_600_scaled_240x135", 240, 135, setup=_offset_scene((-610.0, 12.0, 580.0), _ANISO)),
+    Case("pair_skip_offset_30000_240x135", 240, 135, setup=_offset_scene((30000.0, 0.0, -30000.0))),
+    Case("pair_skip_offset_4e6_160x90", 160, 90, setup=_offset_scene((4.0e6, 1.0e6, 4.0e6))),
     Case("pair_skip_negative_scale_200x112", 200, 112, setup=_scaled_unrotated([(1.3, -0.8, 1.1), (0.7, 1.9, 1.2), (0.9, 1.1, 1.05), (1.6, 0.6, 1.0)])),
     Case("pair_skip_zero_scale_200x112", 200, 112, setup=_scaled_unrotated([(1.3, 0.8, 1.1), (0.7, 0.0, 1.2), (0.9, 1.1, 1.05), (1.6, 0.6, 1.0)])),
     Case("pair_skip_inf_scale_200x112", 200, 112, setup=_scaled_unrotated([(float("inf"), 0.8, 1.1), (0.7, 1.9, 1.2), (0.9, 1.1, 1.05), (1.6, 0.6, 1.0)])),
