@@ -1272,10 +1272,10 @@ int rm_blit_wait(rm_ctx *c, long long ticket) {
     RM_TRY
     if (!c) return RM_E_ARG;
     if (ticket < 0 || ticket >= c->async_issued) return fail(c, RM_E_ARG, "rm_blit_wait: no such ticket");
-    if (ticket < c->async_issued - 2) return RM_OK;       // its set has been reused since, which waited for it
     DeviceScope ds;
     RM_HIP(c, ds.enter(c->device));
-    // (if the set has been reused by ticket + 2, this waits for that call too: later, never earlier, than asked)
+    // (if the set has been reused by ticket + 2, ticket + 4, ... this waits for the latest of those calls: the set's stream runs
+    // them in order, so that is later, never earlier, than asked)
     RM_HIP(c, hipEventSynchronize(c->ev_done[ticket & 1]));
     return RM_OK;
     RM_CATCH(c)

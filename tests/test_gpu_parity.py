@@ -978,6 +978,22 @@ def test_async_host_blit_equals_rm_blit(oracle, torch_cuda, name):
         mat._ck(lib.rm_blit_wait(mat.handle, t0.value))
         got = {"rgba": ar.reshape(case.h, case.w, 4).copy(), "depth": ad.reshape(case.h, case.w).copy(), "hit": ah.reshape(case.h, case.w).copy()}
         assert_frame_equal(got, ref, "large async before the small one")
+        # four frames queued into four sets of buffers without a wait in between, then the OLDEST ticket first: the wait must
+        # not return before that frame is in host memory although its staging set has been reused since
+        case.bind(mat)
+        extra = (np.zeros(n * 4, np.uint8), np.zeros(n, np.float32), np.zeros(n, np.uint8))
+        four = [s_[3:6] for s_ in sets] + [extra]
+        for ar_, ad_, ah_ in four:
+            ar_[:] = 0; ad_[:] = 0; ah_[:] = 0
+        tk = []
+        for ar_, ad_, ah_ in four:
+            t = C.c_longlong(-1)
+            mat._ck(lib.rm_blit_async(mat.handle, sp, dp, ar_.ctypes.data, ad_.ctypes.data, ah_.ctypes.data, case.w, case.h, C.byref(t)))
+            tk.append(t.value)
+        for i, (ar_, ad_, ah_) in enumerate(four):
+            mat._ck(lib.rm_blit_wait(mat.handle, tk[i]))
+            got = {"rgba": ar_.reshape(case.h, case.w, 4).copy(), "depth": ad_.reshape(case.h, case.w).copy(), "hit": ah_.reshape(case.h, case.w).copy()}
+            assert_frame_equal(got, ref, f"{name} four queued, frame {i}")
         for pr, pd, ph, _, _, _, pinned in sets:
             if pinned:
                 for p_ in (pr, pd, ph):
