@@ -130,7 +130,7 @@ def test_error_codes_without_gpu_calls():
         assert lib.rm_set_primitives(m.handle, prim, 1) == native.RM_E_ARG
         assert lib.rm_set_primitives(m.handle, prim, native.RM_MAX_PRIMS + 1) == native.RM_E_RANGE
         assert lib.rm_set_kernel(m.handle, 99) == native.RM_E_ARG
-        for k in range(6):                                   # 0 automatic, 1..3 and 5 exact kernels, 4 the tolerance kernels
+        for k in range(6):                                   # 0 automatic, 1..3 and 5 exact kernels, 4 the tolerance kernel
             assert lib.rm_set_kernel(m.handle, k) == native.RM_OK
         assert lib.rm_set_kernel(m.handle, 6) == native.RM_E_ARG and lib.rm_set_kernel(m.handle, -1) == native.RM_E_ARG
         # the transport entry points check their arguments before they touch the GPU
