@@ -557,6 +557,29 @@ def run_single(args) -> None:
         m9.close(); m9b.close(); mat9a.close()
         del f9, f9b
 
+        # ---- frames WITHOUT a previous frame of their shape (a context's first frame, a resize): the frame height alternates between
+        # h and h - 8 rows, so every launch starts from cleared queue state; with the tile-cost prediction pass and without ----
+        nh_ = {}
+        for (ww, hh) in ((w, h), (1920, 1080)):
+            fr_n = Frame(torch, dev, ww, hh)
+            for label, floats in (("predicted", {}), ("unordered", {"_RmPredictTiles": 0.0})):
+                mn = default_material(ww, hh)
+                for k_, v_ in floats.items():
+                    mn.SetFloat(k_, v_)
+
+                def step_nh(_i, mn=mn, fr_n=fr_n, ww=ww, hh=hh):
+                    mn._ck(lib.rm_blit_device(mn.handle, None, None, _ptr(fr_n.color), _ptr(fr_n.depth), _ptr(fr_n.hit), ww, hh - 8, stream))
+                    mn._ck(lib.rm_blit_device(mn.handle, None, None, _ptr(fr_n.color), _ptr(fr_n.depth), _ptr(fr_n.hit), ww, hh, stream))
+
+                el, ms = timed(torch, step_nh, Ks, Ws, ramp_s=RAMP_S)
+                nh_[f"{ww}x{hh}_{label}_ms_per_frame"] = ms / 2.0
+                mn.close()
+            del fr_n
+        sec["frames_without_history"] = dict(nh_, what="ms per frame when no launch finds a previous frame of its own shape (two frame heights in turn): "
+                                             "the persistent kernel's queue ordered by the prediction pass (one capped ray per 8x8 tile, "
+                                             "run ahead of the frame and included in the time) against the plain scattered order; "
+                                             "the headline and default_1080p are the same frames WITH history")
+
         # ---- the shadow map consumed: depth pass from the light + frame whose shadow term is a lookup (_RmShadowMode 1 / 2) ----
         from raymarching_amd import ShadowMap
         from raymarching_amd.unity import Matrix4x4

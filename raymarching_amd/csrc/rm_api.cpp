@@ -74,6 +74,10 @@ struct QueueState {
     bool dirty = false;            // a queue launch failed: counters/lists are in an unknown rotation state
     bool history = false;          // the last launch appended tile costs for a frame of the shape below
     uint32_t last_tiles = 0, last_tx = 0, last_ty = 0; int last_mode = -1;
+    // what the last single-view frame of the 4-slot scene looked at: a frame that looks elsewhere gets predicted tile costs
+    // instead of that frame's (launch_queue)
+    bool have_view = false;
+    RmView last_view; float last_pos[4][3]; float last_light[3];
 };
 
 // Device memory a launch works in beyond the caller's images: queue state, counter slots, reduced counters.
@@ -632,6 +636,43 @@ constexpr size_t queue_words(uint32_t bm_cap) { return RM_Q_HDR + 3 * (size_t)RM
 // not fit a workgroup) and the caller did not insist on it
 constexpr int RM_FALLBACK_TILE = 1;
 
+// Image coordinates (u, v in [0,1] inside the frame) of world point p under view V: a * (p - ro) = bl + u*(br - bl) + v*(tl - bl).
+// false for a point behind the camera or a degenerate view.
+bool project_to_view(const RmView &V, const float p[3], float &u, float &v) {
+    const double ex[3] = {(double)V.br[0] - V.bl[0], (double)V.br[1] - V.bl[1], (double)V.br[2] - V.bl[2]};
+    const double ey[3] = {(double)V.tl[0] - V.bl[0], (double)V.tl[1] - V.bl[1], (double)V.tl[2] - V.bl[2]};
+    const double d[3] = {(double)p[0] - V.ro[0], (double)p[1] - V.ro[1], (double)p[2] - V.ro[2]};
+    const double b[3] = {V.bl[0], V.bl[1], V.bl[2]};
+    auto det3 = [](const double *x, const double *y, const double *z) {
+        return x[0] * (y[1] * z[2] - y[2] * z[1]) - x[1] * (y[0] * z[2] - y[2] * z[0]) + x[2] * (y[0] * z[1] - y[1] * z[0]);
+    };
+    // u*ex + v*ey + a*(-d) = -bl
+    const double nd[3] = {-d[0], -d[1], -d[2]}, nb[3] = {-b[0], -b[1], -b[2]};
+    const double D = det3(ex, ey, nd);
+    if (!(std::fabs(D) > 1e-30)) return false;
+    const double uu = det3(nb, ey, nd) / D, vv = det3(ex, nb, nd) / D, a = det3(ex, ey, nb) / D;
+    if (!(a > 0.0) || !std::isfinite(uu) || !std::isfinite(vv)) return false;
+    u = (float)uu; v = (float)vv;
+    return true;
+}
+
+// Has the picture moved by more than a few tiles since the frame whose tile costs the queue state holds?  The four primitives'
+// positions are projected with both views; a light that turned counts too (the long tiles are shadow marches).  Only orders
+// the queue: a wrong answer costs time, never a pixel.
+bool looks_elsewhere(const QueueState &S, const RmParams &P) {
+    const float max_shift_px = 4.0f * (float)RM_TW;
+    for (int i = 0; i < 4; i++) {
+        const float pn[3] = {P.prims4[i].px, P.prims4[i].py, P.prims4[i].pz};
+        float u0, v0, u1, v1;
+        const bool ok0 = project_to_view(S.last_view, S.last_pos[i], u0, v0), ok1 = project_to_view(P.view, pn, u1, v1);
+        if (ok0 != ok1) return true;
+        if (ok0 && (std::fabs(u1 - u0) * (float)P.w > max_shift_px || std::fabs(v1 - v0) * (float)P.h > max_shift_px)) return true;
+    }
+    double dl = 0.0, l2 = 0.0;
+    for (int k = 0; k < 3; k++) { const double d = (double)P.light[k] - S.last_light[k]; dl += d * d; l2 += (double)P.light[k] * P.light[k]; }
+    return !(dl <= 0.0025 * l2);          // more than 5 % of its length (NaN lights included)
+}
+
 int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, int family, WorkMem &M, bool forced) {
     const bool streamk = family == RM_KERNEL_STREAM, fast = family == RM_KERNEL_FAST;
     QueueState &S = *M.q;
@@ -721,6 +762,36 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, int family, WorkMem
         S.zeroed = false;
         S.history = keep_history;
         S.last_mode = P.mode; S.last_tiles = n_tiles; S.last_tx = tx; S.last_ty = ty;
+    }
+
+    // No previous frame to order the queue by -- a context's first frame, another frame size -- or one that looked elsewhere (a
+    // camera cut, a primitive or the light moved far): one ray per tile, marched ahead of the frame, fills the heavy-tile set
+    // the frame kernel is about to read (rm_k_predict.hip).  Without history the three sets are all zero at this point (the
+    // clear above ran, or the buffer has not been used since it was zeroed); with a stale one only the set's count has to be
+    // cleared, the prediction writes every word of its bitmap.
+    {
+        const bool one_view = !P.views && P.n_poses == 1 && P.n_parts == 1;
+        const bool may_predict = !solo && !streamk && keep_history && P.n_prims == 0 && P.body == RM_BODY_PRIMS && P.mode == RM_MODE_FRAG &&
+                                 Q.heavy_threshold != 0xffffffffu && getf(c, "_RmTileFeedback", 1.0f) != 0.0f &&
+                                 getf(c, "_RmPredictTiles", 1.0f) != 0.0f;
+        const bool stale = may_predict && same_shape && one_view && S.have_view && looks_elsewhere(S, P);
+        if (may_predict && (!same_shape || stale)) {
+            // a centre ray at two thirds of the frame kernel's threshold (16 of 24) finds the long tiles without listing the cheap ones
+            const float pt = getf(c, "_RmPredictThreshold", 0.0f);
+            const unsigned p_thr = pt >= 1.0f ? (unsigned)pt : (2u * Q.heavy_threshold + 2u) / 3u;
+            hipError_t pe = stale ? rm_zero_words(Q.heavy_count + Q.hv_cur, 1, stream) : hipSuccess;
+            if (pe == hipSuccess) pe = rm_launch_predict(P, p_thr, stream);
+            if (pe != hipSuccess) { S.dirty = true; S.history = false; return fail(c, RM_E_DEVICE, std::string("tile prediction launch: ") + hipGetErrorString(pe)); }
+            Q.use_history = 1u;
+        }
+        if (!solo) {
+            S.have_view = one_view && P.n_prims == 0 && P.body == RM_BODY_PRIMS;
+            if (S.have_view) {
+                S.last_view = P.view;
+                for (int i = 0; i < 4; i++) { S.last_pos[i][0] = P.prims4[i].px; S.last_pos[i][1] = P.prims4[i].py; S.last_pos[i][2] = P.prims4[i].pz; }
+                for (int k = 0; k < 3; k++) S.last_light[k] = P.light[k];
+            }
+        }
     }
 
     unsigned per_cu = (unsigned)occ_it->second;

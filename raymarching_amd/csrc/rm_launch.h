@@ -47,6 +47,10 @@ hipError_t rm_launch_queue(const RmParams &U, unsigned blocks, hipStream_t strea
 // shadow term looked up in the bound _ShadowMap (U.shadow_mode != 0) instead of marched, 0 = the general kernel (which has no
 // lookup: with U.shadow_mode != 0 only shape 4 may be launched)
 int rm_queue_shape(const RmParams &U);
+// Tile costs without a previous frame (4-slot scenes): marches the centre ray of every 8x8 tile of the launch U describes until
+// it has cost `threshold` scene evaluations and lists the tiles whose ray got there in heavy-tile set U.queue.hv_cur (which must
+// be clear), as the previous frame of rm_launch_queue would have
+hipError_t rm_launch_predict(const RmParams &U, unsigned threshold, hipStream_t stream);
 int rm_variant_index(const RmParams &U);
 
 // persistent kernel with lane-level ray compaction; same calling convention as rm_launch_queue

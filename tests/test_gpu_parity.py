@@ -480,6 +480,62 @@ def test_tile_history_does_not_change_output(oracle, torch_cuda, name):
                 assert got["stats"]["sum_steps_p"] == ref["stats"]["sum_steps_p"]
 
 
+@pytest.mark.parametrize("threshold", [0.0, 1.0, 5.0, 200.0])
+def test_predicted_tile_order_does_not_change_output(oracle, torch_cuda, threshold):
+    """a frame without a previous one of its shape, and a frame after a camera cut, have their queue ordered by a prediction
+    pass (one ray per tile): whatever it lists -- nothing (threshold 200), nearly every tile (1), more tiles than the list
+    holds -- every frame is the oracle's; the same sequence with the pass switched off gives the same bytes"""
+    from raymarching_amd import Material, Raymarching, scenes
+    from raymarching_amd.material import _ptr, current_stream_handle
+    torch = torch_cuda
+    w, h = 1536, 864                      # 20736 tiles: more than the list's 8192 entries when (almost) all are listed
+    poses = [0, 0, 23, 23, 24, 5]         # first frame; history; cut; history; small move; cut
+    refs = {}
+    for k in set(poses):
+        case = cases.Case(f"orbit_k{k}_{w}x{h}", w, h, setup=cases._orbit(k))
+        refs[k] = cases.oracle_run(case, oracle)
+    stream = current_stream_handle("cuda:0")
+    outs = {}
+    for predict in (1.0, 0.0):
+        with Material() as mat:
+            mat.set_kernel(KERNELS["queue"])
+            mat.SetFloat("_RmPredictTiles", predict)
+            if threshold > 0.0:
+                mat.SetFloat("_RmPredictThreshold", threshold)
+            c = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda:0")
+            d = torch.zeros((h, w), dtype=torch.float32, device="cuda:0")
+            hm = torch.zeros((h, w), dtype=torch.uint8, device="cuda:0")
+            for i, k in enumerate(poses):
+                cases.Case(f"orbit_k{k}_{w}x{h}", w, h, setup=cases._orbit(k)).bind(mat)
+                mat.SetFloat("_RmPredictTiles", predict)
+                if threshold > 0.0:
+                    mat.SetFloat("_RmPredictThreshold", threshold)
+                mat._ck(mat._lib.rm_blit_device(mat.handle, None, None, _ptr(c), _ptr(d), _ptr(hm), w, h, stream))
+                torch.cuda.synchronize()
+                got = {"rgba": c.cpu().numpy(), "depth": d.cpu().numpy(), "hit": hm.cpu().numpy()}
+                assert_frame_equal(got, refs[k], f"predict {predict} frame {i} pose {k}")
+                st = mat.stats()
+                assert st["n_hit"] == refs[k]["stats"]["n_hit"] and st["sum_steps_p"] == refs[k]["stats"]["sum_steps_p"]
+                assert st["sum_steps_s"] == refs[k]["stats"]["sum_steps_s"]
+                outs[(predict, i)] = sha(got["rgba"])
+    assert all(outs[(1.0, i)] == outs[(0.0, i)] for i in range(len(poses)))
+
+
+@pytest.mark.parametrize("name", ["default_src_depth_640x360", "shadowmap_lookup_dir_320x180", "shadowmap_lookup_persp_320x180", "tiny_17x3", "wide_1025x2", "transformed_400x225",
+                                  "pair_skip_scaled_400x225", "edge_nan_camera_32x18"])
+def test_first_frame_prediction_on_other_launch_shapes(oracle, torch_cuda, name):
+    """the prediction pass ahead of a context's first frame: with source image and depth texture, with the shadow term looked up,
+    on frames smaller than a tile row, on the rotated / scaled variants, with a camera that is not a number"""
+    if name not in cases.BY_NAME:
+        pytest.skip(f"no case {name}")
+    case = cases.BY_NAME[name]
+    ref = cases.oracle_run(case, oracle)
+    for predict in (1.0, 0.0):
+        got = gpu_run(case, torch_cuda, kernel=KERNELS["queue"], floats={"_RmPredictTiles": predict})
+        assert_frame_equal(got, ref, f"{name} predict {predict}")
+        assert got["stats"]["sum_steps_p"] == ref["stats"]["sum_steps_p"]
+
+
 def test_more_heavy_tiles_than_waves(oracle, torch_cuda):
     """a frame with more tiles than resident waves and a threshold that puts (almost) every tile on the
     heavy list: the part of the list beyond one entry per wave must still be rendered, exactly once"""
