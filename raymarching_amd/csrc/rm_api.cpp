@@ -783,6 +783,7 @@ int launch_queue(rm_ctx *c, RmParams &P, hipStream_t stream, int family, WorkMem
             if (pe == hipSuccess) pe = rm_launch_predict(P, p_thr, stream);
             if (pe != hipSuccess) { S.dirty = true; S.history = false; return fail(c, RM_E_DEVICE, std::string("tile prediction launch: ") + hipGetErrorString(pe)); }
             Q.use_history = 1u;
+            c->floats["_RmPredictedFrames"] = getf(c, "_RmPredictedFrames", 0.0f) + 1.0f;     // read-only diagnostic: frames ordered by a prediction so far
         }
         if (!solo) {
             S.have_view = one_view && P.n_prims == 0 && P.body == RM_BODY_PRIMS;

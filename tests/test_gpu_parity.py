@@ -521,6 +521,46 @@ def test_predicted_tile_order_does_not_change_output(oracle, torch_cuda, thresho
     assert all(outs[(1.0, i)] == outs[(0.0, i)] for i in range(len(poses)))
 
 
+def test_which_frames_get_a_predicted_order(torch_cuda):
+    """the host's decision when the previous frame's tile costs are of no use: a context's first frame and a resize; a camera
+    cut; a primitive moved far; the light turned -- but not the same pose again, a small camera step or a primitive nudged"""
+    from raymarching_amd import Material, Raymarching, scenes
+    from raymarching_amd.material import _ptr, current_stream_handle
+    torch = torch_cuda
+    w, h = 640, 360
+    stream = current_stream_handle("cuda:0")
+    c = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda:0")
+    d = torch.zeros((h, w), dtype=torch.float32, device="cuda:0")
+    hm = torch.zeros((h, w), dtype=torch.uint8, device="cuda:0")
+    with Material() as mat:
+        mat.set_kernel(KERNELS["queue"])
+
+        def frame(k=0, hh=h, move=None, light=scenes.WORLD_SPACE_LIGHT_POS0):
+            ts = scenes.default_transforms()
+            if move is not None:
+                ts[0].position = (np.asarray(ts[0].position, dtype=np.float32) + np.asarray(move, dtype=np.float32)).astype(np.float32)
+            Raymarching(scenes.orbit_camera(k, 720, w, hh), mat, ts).bind()          # 720 poses: half a degree per pose
+            mat.SetVector("_WorldSpaceLightPos0", np.asarray(light, dtype=np.float32))
+            mat._ck(mat._lib.rm_blit_device(mat.handle, None, None, _ptr(c), _ptr(d), _ptr(hm), w, hh, stream))
+            torch.cuda.synchronize()
+            return int(mat.GetFloat("_RmPredictedFrames"))        # read-only diagnostic the library keeps in the property bag
+
+        assert frame(0) == 1                                   # first frame of the context
+        assert frame(0) == 1                                   # the same pose again: history
+        assert frame(1) == 1                                   # half a degree: history
+        assert frame(2, move=(0.01, 0.0, 0.0)) == 1            # a primitive nudged: history
+        assert frame(90) == 2                                  # 44 degrees further: cut
+        assert frame(90) == 2
+        assert frame(90, move=(3.0, 0.0, 0.0)) == 3            # a primitive carried across the picture
+        assert frame(90, move=(3.0, 0.0, 0.0)) == 3
+        lt = np.asarray(scenes.WORLD_SPACE_LIGHT_POS0, dtype=np.float32).copy(); lt[0] += 0.5
+        assert frame(90, move=(3.0, 0.0, 0.0), light=lt) == 4  # the light turned
+        assert frame(90, move=(3.0, 0.0, 0.0), light=lt) == 4
+        assert frame(90, hh=h - 8, move=(3.0, 0.0, 0.0), light=lt) == 5      # another frame size
+        mat.SetFloat("_RmPredictTiles", 0.0)
+        assert frame(400, hh=h) == 5                           # switched off: no prediction whatever happens
+
+
 @pytest.mark.parametrize("name", ["default_src_depth_640x360", "shadowmap_lookup_dir_320x180", "shadowmap_lookup_persp_320x180", "tiny_17x3", "wide_1025x2", "transformed_400x225",
                                   "pair_skip_scaled_400x225", "edge_nan_camera_32x18"])
 def test_first_frame_prediction_on_other_launch_shapes(oracle, torch_cuda, name):
