@@ -296,6 +296,13 @@ int rm_debug_counter_slots(rm_ctx *ctx, uint32_t *out, int max_words, int *words
  * opt-in tolerance kernel for the reference's 4-slot scene (fused multiply-adds and hardware sqrt/rcp in the two march
  * loops): frames within the port's tolerance, not bit-identical; every other scene is rendered by the exact kernels. */
 int rm_set_kernel(rm_ctx *ctx, int variant);
+/* Tile order of the persistent kernel (no counterpart in the reference; none of this changes a pixel): a frame is rendered with
+ * the tiles that were expensive in the context's previous frame first.  A frame without a usable previous one -- the first of a
+ * context, another frame size, a camera cut, a primitive or the light moved far -- is preceded by a short pass that marches one
+ * ray per 8x8 tile and supplies that order.  Float properties: _RmTileFeedback 0 renders every frame in the plain scattered
+ * order, _RmPredictTiles 0 switches the pass off, _RmHeavyTileThreshold (default 24) and _RmPredictThreshold (default two thirds
+ * of it) are the costs in scene evaluations from which a tile counts as expensive.  rm_get_float(ctx, "_RmPredictedFrames", &n)
+ * reads how many frames were ordered by the pass so far (an error before the first). */
 
 /* Unity's native-plugin loader calls these two, if a plugin exports them, when it loads and unloads the
  * library (Unity's IUnityInterface.h).  The scripts this library replaces (Assets/Raymarching.cs,
