@@ -668,12 +668,17 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
             if (x < U.w && yl < U.rows) { po = rm_compute_pixel(U, sc, x, yl, (int)pose, t_hit, t_p, t_s, sv, use_sv); have = true; }
             c_hit += t_hit; c_p += t_p; c_s += t_s;
         }
-        // 3. the claim has had the whole tile to come back; read it before the stores go out
-        if (claiming) {
+        // 3. the claim has had the whole tile to come back; read it before the stores go out.  The register is read on every
+        // path, claim or not: with the read under `if (claiming)` the compiler cannot see that an issued claim is always
+        // consumed, keeps the register's pending write alive across the loop's back edge and puts an s_waitcnt vmcnt(0) ahead
+        // of the next iteration's first write to it -- and since stores share that counter, every tile then began by waiting
+        // for the acknowledgement of the previous tile's framebuffer stores.
 #ifdef RM_TIMELINE
-            const unsigned long long tw0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long tw0 = __builtin_amdgcn_s_memrealtime();
 #endif
-            unsigned k = __builtin_amdgcn_readfirstlane(k_raw);
+        const unsigned k_seen = __builtin_amdgcn_readfirstlane(k_raw);
+        if (claiming) {
+            unsigned k = k_seen;
 #ifdef RM_TIMELINE
             asm volatile("" :: "s"(k));
             t_wait += (unsigned)(__builtin_amdgcn_s_memrealtime() - tw0); n_claims++;

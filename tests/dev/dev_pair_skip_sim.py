@@ -45,6 +45,10 @@ def march(ox, oy, oz, dx, dy, dz, active, shadow):
             s01, _ = NP.smin_w(o0, o1)
             full, _ = NP.smin_w(s01, s23)
             steps += 1
+            if shadow and bool(np.all((o2 - o3 >= f(.5))[active])):
+                LINK[0] += 1                                 # the link lies .5 above the cylinder for every marching ray
+            if shadow:
+                LINK[1] += 1
             # the rule that needs no evaluation at all: bounds of both halves carried from the previous step
             if bool(np.all((lb - ub >= (np.abs(lb) + np.abs(ub)) * f(1e-4) + f(.51))[active])):
                 predicted += 1
@@ -65,6 +69,7 @@ def march(ox, oy, oz, dx, dy, dz, active, shadow):
     return steps, skipped, ev, dm, predicted
 
 tot = np.zeros(6)
+LINK = [0, 0]
 th, tw = h // 8, w // 8
 for ty in range(0, th, stride):
     for tx in range(0, tw, stride):
@@ -90,4 +95,5 @@ for ty in range(0, th, stride):
             tot[2:4] += [ss, ks]; tot[5] += ps
 print("sample of %d tiles: primary wave steps %d, pair skipped in %.1f %%; shadow wave steps %d, pair skipped in %.1f %%" %
       (len(range(0, th, stride)) * len(range(0, tw, stride)), tot[0], 100 * tot[1] / tot[0], tot[2], 100 * tot[3] / max(tot[2], 1)))
+print("shadow wave steps in which the link lies .5 above the cylinder for every marching ray: %d of %d" % (LINK[0], LINK[1]))
 print("decided before the evaluation (bounds of both halves): primary %.1f %%, shadow %.1f %%" % (100 * tot[4] / tot[0], 100 * tot[5] / max(tot[2], 1)))
