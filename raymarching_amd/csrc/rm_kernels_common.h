@@ -609,6 +609,12 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
     };
     auto chunk_first = [&](unsigned k, unsigned s) -> unsigned { return static_end + (k * RM_Q_SHARDS + s) * RM_Q_CHUNK; };
 
+    // A wave whose claim finds its shard exhausted goes on to the other shards only in pose batches and in launches too small
+    // to have waves on every shard.  In a single frame the shards -- interleaved chunk lists over scattered tiles -- run dry
+    // within a few chunks of each other, and each is drained by its own 512 waves; the looks and failed claims of 4096
+    // waves touring the other seven were the frame's last 2 % (4K 240 -> 236 us, 1080p 83.5 -> 81.5 us, and two frames in
+    // flight 224 -> 212 us per frame: the tour's memory-side operations also stood in the way of the other frame's claims).
+    const bool steal = SHAPE == 2 || (!PLAIN && U.n_poses != 1) || gridDim.x < 4u * RM_Q_SHARDS;
     bool done = false;
     unsigned cur = gw < n_first ? gw : local_next();
     if (cur == 0xffffffffu) {
@@ -617,7 +623,7 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
         if (lane == 0) k = atomicAdd(&counters[shard * RM_Q_STRIDE], 1u);
         k = __builtin_amdgcn_readfirstlane(k);
         cur = chunk_first(k, shard);
-        if (cur >= n_entries) { cur = 0xffffffffu; dry |= 1u << shard; }
+        if (cur >= n_entries) { cur = 0xffffffffu; dry |= 1u << shard; if (!steal) dry = (1u << RM_Q_SHARDS) - 1u; }
         else { unsigned last = cur + RM_Q_CHUNK < n_entries ? cur + RM_Q_CHUNK : n_entries; dyn_next = cur + 1; dyn_left = last - cur - 1; }
     }
     while (!done) {
@@ -633,6 +639,9 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
         // has to learn that every shard is empty; as atomics those are thousands of same-address
         // operations that L2 serialises (~5 ns each, a 10-20 us tail on the frame), as loads they are
         // served in parallel.  The wave has nothing else to do at this point, so the loads are waited for.
+        // (One shard at a time on purpose: with lane s looking at shard s, all eight in one round trip, every look of every
+        // wave lands on every counter's line, and operations on one line queue up in the L2 behind the claims in flight:
+        // +36 us per frame, measured.)
         while (nxt == 0xffffffffu && dry != 0u && dry != (1u << RM_Q_SHARDS) - 1u) {
             while (dry & (1u << shard)) shard = (shard + 1) % RM_Q_SHARDS;
             unsigned seen = 0;
@@ -689,6 +698,7 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
                 nxt = first; dyn_next = first + 1; dyn_left = last - first - 1;
             } else {
                 dry |= 1u << shard;                       // try the next shard on the next round
+                if (!steal) dry = (1u << RM_Q_SHARDS) - 1u;
                 nxt = 0xffffffffu;
                 if (dry == (1u << RM_Q_SHARDS) - 1u) done = true;
             }
