@@ -520,7 +520,7 @@ RM_DI void rm_pixel(const RmParams &U, const S &sc) {
 //  * the static part (Q.static_per_wave entries per non-heavy wave, dealt cyclically) needs no
 //    atomics.  A device-scope returning atomic is a memory-side operation here (1-3 us, about
 //    90 per us and word): far too slow to claim every 3-us tile that way;
-//  * the dynamic part is claimed RM_Q_CHUNK entries at a time from RM_Q_SHARDS counters, each
+//  * the dynamic part is claimed RM_Q_CHUNK entries (single frames: two) at a time from RM_Q_SHARDS counters, each
 //    on its own 256-B line, by waves that have run out of static work; it evens out what the
 //    static deal left unbalanced.  The claiming atomic is issued BEFORE the current tile is
 //    rendered and its result is read after, ahead of the tile's framebuffer stores, so its
@@ -607,7 +607,11 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
         if (dyn_left) { dyn_left--; return dyn_next++; }
         return 0xffffffffu;
     };
-    auto chunk_first = [&](unsigned k, unsigned s) -> unsigned { return static_end + (k * RM_Q_SHARDS + s) * RM_Q_CHUNK; };
+    // Entries per claim: RM_Q_CHUNK, but two in the single-frame shapes.  A finer deal ends a frame more evenly (4K 235 -> 231 us,
+    // 1080p 82 -> 81 us); a pose batch has eight times the tiles and pays for twice the claims instead (8 poses at 4K in one
+    // launch: 230 -> 242 us per pose with two, 232 with three), so it keeps four.
+    constexpr unsigned CHUNK = (SHAPE == 1 || SHAPE == 3 || SHAPE == 4) ? (RM_Q_CHUNK < 2 ? RM_Q_CHUNK : 2) : RM_Q_CHUNK;
+    auto chunk_first = [&](unsigned k, unsigned s) -> unsigned { return static_end + (k * RM_Q_SHARDS + s) * CHUNK; };
 
     // A wave whose claim finds its shard exhausted goes on to the other shards only in pose batches and in launches too small
     // to have waves on every shard.  In a single frame the shards -- interleaved chunk lists over scattered tiles -- run dry
@@ -624,7 +628,7 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
         k = __builtin_amdgcn_readfirstlane(k);
         cur = chunk_first(k, shard);
         if (cur >= n_entries) { cur = 0xffffffffu; dry |= 1u << shard; if (!steal) dry = (1u << RM_Q_SHARDS) - 1u; }
-        else { unsigned last = cur + RM_Q_CHUNK < n_entries ? cur + RM_Q_CHUNK : n_entries; dyn_next = cur + 1; dyn_left = last - cur - 1; }
+        else { unsigned last = cur + CHUNK < n_entries ? cur + CHUNK : n_entries; dyn_next = cur + 1; dyn_left = last - cur - 1; }
     }
     while (!done) {
         // 1. the entry after `cur`: from the wave's own stock, or by an atomic issued now and read in step 3
@@ -694,7 +698,7 @@ RM_DI void rm_queue_body(const RmParams &U, const S &sc) {
 #endif
             unsigned first = chunk_first(k, shard);
             if (first < n_entries) {
-                unsigned last = first + RM_Q_CHUNK < n_entries ? first + RM_Q_CHUNK : n_entries;
+                unsigned last = first + CHUNK < n_entries ? first + CHUNK : n_entries;
                 nxt = first; dyn_next = first + 1; dyn_left = last - first - 1;
             } else {
                 dry |= 1u << shard;                       // try the next shard on the next round
